@@ -1,0 +1,36 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def load_golden(name):
+    return np.load(os.path.join(GOLDEN, name + ".npz"))
+
+
+@pytest.fixture(scope="session")
+def golden():
+    return load_golden
+
+
+def rel_err(a, b):
+    a = np.asarray(a).ravel()
+    b = np.asarray(b).ravel()
+    return float(np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300))
+
+
+def circ_err(xa, xb, L):
+    """max distance on the circle of circumference L (x=0 and x=L-eps are neighbours)."""
+    d = np.abs(np.asarray(xa, dtype=float).ravel() - np.asarray(xb, dtype=float).ravel())
+    return float(np.max(np.minimum(d, L - d)))
