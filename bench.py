@@ -1,0 +1,180 @@
+#!/usr/bin/env python3
+"""Headline benchmark: particle-steps/s of the PIC step (PIC.update_state of the reference) on
+BASELINE config 2 -- bump-on-tail, N = 1e6 particles, Ng = 256, 64 environments per GPU, fp64.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One rank per GPU; environments are sharded (64 per rank, weak scaling), no collective inside the
+step; the only RCCL traffic is the all-gather of per-environment returns after the K steps.
+Rank 0 prints ONE JSON line (contract in DESIGN.md "Measurement").
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0                 # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+BYTES_PER_PARTICLE_STEP = {"float64": 112, "float32": 56}   # 14 words: 4 reads + 3 writes of (x, v)
+# algorithmic particle-array words moved by one launch of each sweep (reads + writes of x and v)
+SWEEP_WORDS = {"sweep_A": 2, "sweep_B": 4, "sweep_C": 4, "sweep_D": 4}
+
+
+def synth_bump_on_tail_device(torch, num_envs, N, L, dtype, device, seed, a=0.2, vb=3.0, vth=1.0, A=0.1, n_mode=2):
+    """SURVEY 8d synthetic ensemble, generated on the device: x ~ U[0,L), v a 1/(1+a) : a/(1+a)
+    mixture of N(0,1) and N(vb, vth^2), then v *= 1 + A sin(2 pi n_mode x / L) (pic.py:68)."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    x = torch.rand((num_envs, N), generator=g, device=device, dtype=torch.float64) * L
+    x = torch.clamp(x, max=float(np.nextafter(L, 0.0)))
+    v = torch.randn((num_envs, N), generator=g, device=device, dtype=torch.float64)
+    n1 = int(N * (1 / (1 + a)))
+    v[:, n1:] = v[:, n1:] * vth + vb
+    v *= 1 + A * torch.sin(2 * np.pi * n_mode * x / L)
+    return x.to(dtype).contiguous(), v.to(dtype).contiguous()
+
+
+def cpu_baseline(N, Ng, L, dt, budget_s=20.0):
+    """The NumPy oracle with the reference's call structure (7 compute_E + refresh per step, dense
+    Ng x Ng operators, np.bincount), one thread, on a bounded sample of the same workload."""
+    from oracle import pic_oracle as po
+    x0, v0 = po.synthetic_bump_on_tail(N, L, seed=1234)
+    sim = po.OraclePIC(x0, v0, Ng, L=L, dt=dt, perturb=False, faithful=True)
+    t0 = time.perf_counter()
+    sim.update_state(None)
+    one = time.perf_counter() - t0
+    steps = int(max(2, min(30, budget_s / max(one, 1e-3))))
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        sim.update_state(None)
+    el = time.perf_counter() - t0
+    return {"value": N * steps / el, "unit": "particle-steps/s", "cores": 1, "kind": "port",
+            "sample": f"1 env of N={N}, Ng={Ng}, {steps} steps of the NumPy oracle (faithful call structure), "
+                      f"{el / steps * 1e3:.0f} ms/step"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--envs", type=int, default=64, help="environments per GPU")
+    ap.add_argument("--particles", type=int, default=1_000_000)
+    ap.add_argument("--mesh", type=int, default=256)
+    ap.add_argument("--dtype", default="float64", choices=["float64", "float32"])
+    ap.add_argument("--accum", default=None, choices=[None, "float64", "float32"])
+    ap.add_argument("--blocks-per-env", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile-steps", type=int, default=3)
+    args = ap.parse_args()
+
+    import torch
+    import ocplasma_amd
+    from ocplasma_amd.env.batched import BatchedPIC
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the PIC step has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+
+    N, Ng, E, L = args.particles, args.mesh, args.envs, 50.0
+    tdtype = torch.float64 if args.dtype == "float64" else torch.float32
+    env = BatchedPIC(E, N, Ng, L=L, dt=0.1, device=local_rank, dtype=args.dtype, accum_dtype=args.accum,
+                     blocks_per_env=args.blocks_per_env)
+    x0, v0 = synth_bump_on_tail_device(torch, E, N, L, tdtype, f"cuda:{local_rank}", seed=1234 + rank)
+    torch.cuda.synchronize()
+    env.reset_device(x0.data_ptr(), v0.data_ptr())
+    env.sync()
+    del x0, v0
+    ke0, pe0, _ = env.energies()
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        env.sync()
+
+    env.step(None, nsteps=args.warmup)
+    barrier()
+    t0 = time.perf_counter()
+    env.step(None, nsteps=args.steps)
+    env.sync()
+    returns = torch.as_tensor(env.rewards(), device=f"cuda:{local_rank}")
+    if dist is not None:
+        gathered = [torch.empty_like(returns) for _ in range(world)]
+        dist.all_gather(gathered, returns)          # the one collective: per-environment returns
+        returns = torch.cat(gathered)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device=f"cuda:{local_rank}", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # health: nothing non-finite, energy conserved over the run
+    ke, pe, _ = env.energies()
+    drift = float(np.max(np.abs((ke + pe) / (ke0 + pe0) - 1)))
+    bad = env.bad_count()
+
+    # per-kernel durations, HIP events on the library's own stream (untimed extra steps)
+    roof = None
+    kernels = {}
+    if rank == 0 and args.profile_steps > 0:
+        env.profile(True)
+        env.step(None, nsteps=args.profile_steps)
+        prof = env.profile_read()
+        env.profile(False)
+        esz = 8 if args.dtype == "float64" else 4
+        for k, (ms, cnt) in prof.items():
+            kernels[k] = {"avg_ms": ms / cnt, "launches": cnt}
+        dom = max((k for k in prof if k in SWEEP_WORDS), key=lambda k: prof[k][0])
+        avg_s = prof[dom][0] / prof[dom][1] * 1e-3
+        alg_bytes = SWEEP_WORDS[dom] * esz * N * E
+        ach = alg_bytes / avg_s / 1e9
+        roof = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": ach / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": alg_bytes,
+                "avg_launch_ms": avg_s * 1e3}
+
+    total_ps = N * E * world * args.steps
+    value = total_ps / elapsed
+    out = {
+        "metric": "particle-steps/sec (N x envs x steps) at N=1e6, Ng=256; % HBM roofline",
+        "value": value, "unit": "particle-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f64" if args.dtype == "float64" else "f32", "data": "synthetic",
+        "config": {"workload": f"configs[1]: bump-on-tail, N={N}, Ng={Ng}, {E} envs per GPU, {args.dtype}, "
+                               "no control (E_ext = None), Yoshida-4 step = PIC.update_state",
+                   "envs_per_gpu": E, "particles_per_env": N, "mesh": Ng, "dt": env.dt,
+                   "sharding": f"{world} x {E} envs, all-gather of returns only"},
+        "hbm_frac_of_step": value * BYTES_PER_PARTICLE_STEP[args.dtype] / (HBM_PEAK_GBS * 1e9),
+        "energy_drift": drift, "bad_positions": bad, "mean_return": float(returns.mean().item()),
+        "roofline": roof, "kernels": kernels,
+    }
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(N, Ng, L, 0.1)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    env.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,129 @@
+/*
+ * picstep.h -- C ABI of libpicstep.so, the MI355X (gfx950) 1-D electrostatic PIC stepper.
+ *
+ * The reference (ZINZINBIN/Optimal-Control-1D-Electrostatic-Plasma) has no FFI layer: its
+ * boundary is the Python duck type `PIC` (src/env/pic.py:11-223).  Each entry point below names
+ * the reference interface it stands in for; the ctypes binding lives in
+ * optimal-control-1d-electrostatic-plasma_amd/_abi.py and INTEGRATION.md shows the stub a
+ * reference maintainer would add.
+ *
+ * Conventions: every function returns 0 on success or a negative PIC_E* code (text through
+ * pic_last_error); no exception crosses the ABI; the library owns all device memory; host
+ * buffers are caller-owned and copied.  One handle = one device = one HIP stream; calls on one
+ * handle must be serialised by the caller, different handles are independent (one per GPU when
+ * environments are sharded).  All entry points except pic_step / pic_reset (device inputs)
+ * return after the stream has drained; pic_step is asynchronous -- call pic_sync or any getter.
+ *
+ * Particle arrays are [num_envs][ld] with ld >= N (ld from pic_device_ptrs); host copies are
+ * dense [num_envs][N].  Mesh arrays are dense [num_envs][Ng] float64.
+ */
+#ifndef PICSTEP_H
+#define PICSTEP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PICSTEP_ABI_VERSION 1
+
+enum { PIC_F64 = 0, PIC_F32 = 1 };           /* particle / deposit-accumulator dtype          */
+enum { PIC_CIC = 0, PIC_TSC = 1 };           /* src/env/interpolate.py:4 (CIC), :22 (TSC)     */
+enum { PIC_HOST = 0, PIC_DEVICE = 1 };       /* where a caller buffer lives                   */
+
+enum {
+  PIC_OK = 0,
+  PIC_EINVAL = -1,     /* bad argument / unsupported configuration   */
+  PIC_EHIP = -2,       /* a HIP runtime call failed                  */
+  PIC_ESTATE = -3,     /* call order (e.g. step before reset)        */
+  PIC_ENOMEM = -4
+};
+
+/* Constructor arguments of PIC (src/env/pic.py:13-27) that matter to the step, plus batching.
+ * dt is the value AFTER the CFL clamp of pic.py:71-73 (the host wrapper applies the clamp).
+ * gamma is accepted for signature parity only: E_mesh does not depend on it. */
+typedef struct pic_config {
+  int64_t N;               /* particles per environment                                   */
+  int32_t Ng;              /* mesh cells (N_mesh)                                         */
+  int32_t num_envs;        /* independent environments batched on this device             */
+  double  L;               /* box length                                                  */
+  double  n0;              /* mean density                                                */
+  double  dt;              /* time step (post-clamp)                                      */
+  double  gamma;           /* unused by the scan solver                                   */
+  int32_t particle_dtype;  /* PIC_F64 | PIC_F32                                           */
+  int32_t accum_dtype;     /* deposit accumulator in LDS: PIC_F64 | PIC_F32 (F32 needs F32 particles) */
+  int32_t interpol;        /* PIC_CIC | PIC_TSC                                           */
+  int32_t device_id;       /* HIP device ordinal                                          */
+  int32_t blocks_per_env;  /* 0 = choose; workgroups streaming one environment per sweep  */
+  int32_t reserved;
+} pic_config;
+
+typedef struct pic_handle pic_handle;
+
+/* PIC.__init__ (pic.py:13-61) minus sampling: allocates state for num_envs environments. */
+int pic_create(const pic_config* cfg, pic_handle** out);
+int pic_destroy(pic_handle* h);
+
+/* PIC.initialize / reinit (pic.py:63-91) after the host has drawn x0, v0 and applied the velocity
+ * perturbation: stores the particles and does update_density + update_E_field (pic.py:93-123).
+ * x0, v0: [num_envs][N] of the particle dtype, host or device. */
+int pic_reset(pic_handle* h, const void* x0, const void* v0, int mem_kind);
+
+/* nsteps x PIC.update_state(E_external) (pic.py:131-146): Yoshida-4 push
+ * (src/env/integration.py:60-75), final wrap, density/field refresh, KE/PE reductions.
+ * E_ext: NULL or [num_envs][Ng] float64 (held constant over the nsteps), host or device.
+ * Asynchronous on the handle's stream. */
+int pic_step(pic_handle* h, const double* E_ext, int mem_kind, int nsteps);
+
+/* PIC.x / PIC.v / get_state (pic.py:165-167): copies of the particle arrays, dense [num_envs][N]. */
+int pic_get_particles(pic_handle* h, void* x, void* v, int mem_kind);
+/* Overwrite the particles without touching fields (checkpoint restore); follow with pic_refresh. */
+int pic_set_particles(pic_handle* h, const void* x, const void* v, int mem_kind);
+/* update_density + update_E_field on the current particles (pic.py:93-123). */
+int pic_refresh(pic_handle* h);
+
+/* Zero-copy device views for torch: any pointer argument may be NULL. ld = leading dimension
+ * (elements) of x and v; mesh arrays are dense. Valid until pic_destroy. */
+int pic_device_ptrs(pic_handle* h, void** x, void** v, int64_t* ld, double** n, double** E_mesh, double** phi,
+                    double** KE, double** PE, double** PE_reward);
+
+/* PIC.n, PIC.E_mesh, PIC.phi_mesh after a step (pic.py:103,116-117). phi is returned in the
+ * mean-zero gauge (the reference's gauge is round-off). Host buffers, any may be NULL. */
+int pic_get_fields(pic_handle* h, double* n, double* E_mesh, double* phi);
+
+/* Per-environment energies of the current state: KE = 0.5*sum v^2 (src/env/util.py:144),
+ * PE = 0.5*sum(E_mesh^2)*dx*N/L (util.py:129-130), PE_reward = 0.5*sum(E_mesh^2)*dx
+ * (src/control/objective.py:33, the reward reduction). Host buffers [num_envs], any may be NULL. */
+int pic_get_energies(pic_handle* h, double* KE, double* PE, double* PE_reward);
+
+/* PIC.E (pic.py:120): E_mesh gathered at the particles, dense [num_envs][N], particle dtype. */
+int pic_gather_E(pic_handle* h, void* E_particles, int mem_kind);
+
+/* PIC.indx_l/indx_r/weight_l/weight_r (pic.py:104-107) of one environment: host buffers [N]
+ * (int64 indices, float64 weights), any may be NULL. */
+int pic_get_cic(pic_handle* h, int env, int64_t* indx_l, int64_t* indx_r, double* weight_l, double* weight_r);
+
+/* compute_E on arbitrary positions (src/env/util.py:73-116), used by compute_electric_energy
+ * (util.py:119-131) and estimate_electric_energy (objective.py:20-35): deposit x -> solve ->
+ * E_mesh (+E_ext).  Does not modify the environments' state.  x: [num_envs][N] particle dtype;
+ * E_ext: NULL or [num_envs][Ng] host float64; outputs (host, [num_envs][Ng] / [num_envs], any
+ * may be NULL): n, E_mesh (with E_ext added), half_sum_E2_dx = 0.5*sum(E_mesh^2)*dx. */
+int pic_eval_field(pic_handle* h, const void* x, int mem_kind, const double* E_ext,
+                   double* n, double* E_mesh, double* half_sum_E2_dx);
+
+/* Per-kernel timing with HIP events on the handle's stream (bench.py's roofline leg).
+ * kinds: 0..3 = sweeps A..D, 4 = field solve. ms_sum / launches are arrays of 8. */
+int pic_profile(pic_handle* h, int enable);
+int pic_profile_read(pic_handle* h, double* ms_sum, int64_t* launches);
+
+int pic_sync(pic_handle* h);
+/* Number of particle positions found non-finite or out of range by the last sweeps (0 = healthy). */
+int pic_bad_count(pic_handle* h, int64_t* count);
+const char* pic_last_error(pic_handle* h);   /* h may be NULL: error of the last failed pic_create */
+int pic_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PICSTEP_H */

@@ -1,0 +1,226 @@
+"""ctypes binding of include/picstep.h (the only way Python reaches the HIP path).
+
+There is no CPU fallback: if libpicstep.so is missing or no HIP device is
+visible, loading / creating a handle raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _build
+
+PIC_F64, PIC_F32 = 0, 1
+PIC_CIC, PIC_TSC = 0, 1
+PIC_HOST, PIC_DEVICE = 0, 1
+ABI_VERSION = 1
+
+KIND_NAMES = ("sweep_A", "sweep_B", "sweep_C", "sweep_D", "field_solve", "sweep_aux", "", "")
+
+
+class PicConfig(C.Structure):
+    _fields_ = [
+        ("N", C.c_int64), ("Ng", C.c_int32), ("num_envs", C.c_int32),
+        ("L", C.c_double), ("n0", C.c_double), ("dt", C.c_double), ("gamma", C.c_double),
+        ("particle_dtype", C.c_int32), ("accum_dtype", C.c_int32), ("interpol", C.c_int32),
+        ("device_id", C.c_int32), ("blocks_per_env", C.c_int32), ("reserved", C.c_int32),
+    ]
+
+
+class PicError(RuntimeError):
+    pass
+
+
+_lib = None
+
+# name -> argtypes; every entry point of include/picstep.h is listed (tests check the exports)
+_vp, _dp, _i64p = C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)
+SIGNATURES = {
+    "pic_create": [C.POINTER(PicConfig), C.POINTER(_vp)],
+    "pic_destroy": [_vp],
+    "pic_reset": [_vp, _vp, _vp, C.c_int],
+    "pic_step": [_vp, _vp, C.c_int, C.c_int],
+    "pic_get_particles": [_vp, _vp, _vp, C.c_int],
+    "pic_set_particles": [_vp, _vp, _vp, C.c_int],
+    "pic_refresh": [_vp],
+    "pic_device_ptrs": [_vp] + [C.POINTER(_vp)] * 2 + [_i64p] + [C.POINTER(_vp)] * 6,
+    "pic_get_fields": [_vp, _vp, _vp, _vp],
+    "pic_get_energies": [_vp, _vp, _vp, _vp],
+    "pic_gather_E": [_vp, _vp, C.c_int],
+    "pic_get_cic": [_vp, C.c_int, _vp, _vp, _vp, _vp],
+    "pic_eval_field": [_vp, _vp, C.c_int, _vp, _vp, _vp, _vp],
+    "pic_profile": [_vp, C.c_int],
+    "pic_profile_read": [_vp, _dp, _i64p],
+    "pic_sync": [_vp],
+    "pic_bad_count": [_vp, _i64p],
+    "pic_last_error": [_vp],
+    "pic_abi_version": [],
+}
+
+
+def library_path():
+    return _build.LIB
+
+
+def load():
+    """Load csrc/libpicstep.so (built by __graft_entry__.build()); raises if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if not os.path.exists(path):
+        raise PicError(f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                       "(hipcc, gfx950). There is no CPU fallback for the PIC step.")
+    lib = C.CDLL(path)
+    for name, args in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = C.c_char_p if name == "pic_last_error" else C.c_int
+    if lib.pic_abi_version() != ABI_VERSION:
+        raise PicError("libpicstep.so ABI version mismatch: rebuild it")
+    _lib = lib
+    return lib
+
+
+def _ptr(a):
+    if a is None:
+        return None
+    if isinstance(a, int):
+        return C.c_void_p(a)
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Handle:
+    """Owns one pic_handle (one device, one stream, `num_envs` environments)."""
+
+    def __init__(self, N, Ng, num_envs=1, L=50.0, n0=1.0, dt=0.1, gamma=5.0, particle_dtype="float64",
+                 accum_dtype=None, interpol="CIC", device_id=0, blocks_per_env=0):
+        self.lib = load()
+        pd = {"float64": PIC_F64, "float32": PIC_F32}[str(np.dtype(particle_dtype))]
+        ad = pd if accum_dtype is None else {"float64": PIC_F64, "float32": PIC_F32}[str(np.dtype(accum_dtype))]
+        self.cfg = PicConfig(int(N), int(Ng), int(num_envs), float(L), float(n0), float(dt), float(gamma), pd, ad,
+                             {"CIC": PIC_CIC, "TSC": PIC_TSC}[interpol], int(device_id), int(blocks_per_env), 0)
+        self.N, self.Ng, self.num_envs = int(N), int(Ng), int(num_envs)
+        self.dtype = np.dtype(particle_dtype)
+        self._h = C.c_void_p()
+        rc = self.lib.pic_create(C.byref(self.cfg), C.byref(self._h))
+        if rc != 0:
+            msg = self.lib.pic_last_error(None)
+            self._h = C.c_void_p()
+            raise PicError(f"pic_create failed ({rc}): {msg.decode() if msg else ''}")
+
+    def _chk(self, rc):
+        if rc != 0:
+            msg = self.lib.pic_last_error(self._h)
+            raise PicError(f"libpicstep error {rc}: {msg.decode() if msg else ''}")
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self.lib.pic_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- state -------------------------------------------------------------------------------
+    def _particles_in(self, a):
+        a = np.ascontiguousarray(np.asarray(a, dtype=self.dtype).reshape(self.num_envs, self.N))
+        return a
+
+    def reset(self, x0, v0):
+        x0, v0 = self._particles_in(x0), self._particles_in(v0)
+        self._chk(self.lib.pic_reset(self._h, _ptr(x0), _ptr(v0), PIC_HOST))
+
+    def reset_device(self, x_ptr, v_ptr):
+        self._chk(self.lib.pic_reset(self._h, _ptr(int(x_ptr)), _ptr(int(v_ptr)), PIC_DEVICE))
+
+    def set_particles(self, x, v):
+        x, v = self._particles_in(x), self._particles_in(v)
+        self._chk(self.lib.pic_set_particles(self._h, _ptr(x), _ptr(v), PIC_HOST))
+
+    def refresh(self):
+        self._chk(self.lib.pic_refresh(self._h))
+
+    def step(self, E_ext=None, nsteps=1):
+        if E_ext is None:
+            self._chk(self.lib.pic_step(self._h, None, PIC_HOST, int(nsteps)))
+        else:
+            e = np.ascontiguousarray(np.asarray(E_ext, dtype=np.float64).reshape(self.num_envs, self.Ng))
+            self._chk(self.lib.pic_step(self._h, _ptr(e), PIC_HOST, int(nsteps)))
+
+    def step_device(self, E_ext_ptr, nsteps=1):
+        self._chk(self.lib.pic_step(self._h, _ptr(int(E_ext_ptr)) if E_ext_ptr else None, PIC_DEVICE, int(nsteps)))
+
+    def sync(self):
+        self._chk(self.lib.pic_sync(self._h))
+
+    def particles(self):
+        x = np.empty((self.num_envs, self.N), dtype=self.dtype)
+        v = np.empty_like(x)
+        self._chk(self.lib.pic_get_particles(self._h, _ptr(x), _ptr(v), PIC_HOST))
+        return x, v
+
+    def fields(self):
+        n = np.empty((self.num_envs, self.Ng))
+        E = np.empty_like(n)
+        phi = np.empty_like(n)
+        self._chk(self.lib.pic_get_fields(self._h, _ptr(n), _ptr(E), _ptr(phi)))
+        return n, E, phi
+
+    def energies(self):
+        ke = np.empty(self.num_envs)
+        pe = np.empty_like(ke)
+        per = np.empty_like(ke)
+        self._chk(self.lib.pic_get_energies(self._h, _ptr(ke), _ptr(pe), _ptr(per)))
+        return ke, pe, per
+
+    def gather_E(self):
+        E = np.empty((self.num_envs, self.N), dtype=self.dtype)
+        self._chk(self.lib.pic_gather_E(self._h, _ptr(E), PIC_HOST))
+        return E
+
+    def cic(self, env=0):
+        jl = np.empty(self.N, dtype=np.int64)
+        jr = np.empty_like(jl)
+        wl = np.empty(self.N)
+        wr = np.empty_like(wl)
+        self._chk(self.lib.pic_get_cic(self._h, int(env), _ptr(jl), _ptr(jr), _ptr(wl), _ptr(wr)))
+        return jl, jr, wl, wr
+
+    def eval_field(self, x, E_ext=None):
+        """compute_E on arbitrary positions -> (n, E_mesh(+E_ext), 0.5*sum(E^2)*dx) per env."""
+        x = self._particles_in(x)
+        e = None if E_ext is None else np.ascontiguousarray(np.asarray(E_ext, dtype=np.float64).reshape(self.num_envs, self.Ng))
+        n = np.empty((self.num_envs, self.Ng))
+        E = np.empty_like(n)
+        pe = np.empty(self.num_envs)
+        self._chk(self.lib.pic_eval_field(self._h, _ptr(x), PIC_HOST, _ptr(e), _ptr(n), _ptr(E), _ptr(pe)))
+        return n, E, pe
+
+    def device_ptrs(self):
+        ps = [C.c_void_p() for _ in range(8)]
+        ld = C.c_int64()
+        self._chk(self.lib.pic_device_ptrs(self._h, C.byref(ps[0]), C.byref(ps[1]), C.byref(ld), C.byref(ps[2]),
+                                           C.byref(ps[3]), C.byref(ps[4]), C.byref(ps[5]), C.byref(ps[6]),
+                                           C.byref(ps[7])))
+        names = ("x", "v", "n", "E_mesh", "phi", "KE", "PE", "PE_reward")
+        out = {k: p.value for k, p in zip(names, ps)}
+        out["ld"] = ld.value
+        return out
+
+    def profile(self, enable=True):
+        self._chk(self.lib.pic_profile(self._h, 1 if enable else 0))
+
+    def profile_read(self):
+        ms = (C.c_double * 8)()
+        cnt = (C.c_int64 * 8)()
+        self._chk(self.lib.pic_profile_read(self._h, ms, cnt))
+        return {KIND_NAMES[i]: (ms[i], cnt[i]) for i in range(6) if cnt[i]}
+
+    def bad_count(self):
+        c = C.c_int64()
+        self._chk(self.lib.pic_bad_count(self._h, C.byref(c)))
+        return c.value

@@ -1,0 +1,43 @@
+"""Build libpicstep.so for gfx950 with hipcc, in-tree (csrc/libpicstep.so).
+
+hipcc cross-compiles without a GPU, so this runs in the build container; the
+resulting .so travels to the GPU box with the repo snapshot.
+"""
+import os
+import shutil
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+SRC = os.path.join(HERE, "csrc", "picstep.hip")
+LIB = os.path.join(HERE, "csrc", "libpicstep.so")
+INCLUDE = os.path.join(ROOT, "include")
+
+# -ffp-contract=off: the sub-stage arithmetic must round like the NumPy reference (no FMA fusion)
+FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17",
+         "-Wno-unused-result", "-Wno-unused-value", "-I" + INCLUDE]
+
+
+def needs_build():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [SRC, os.path.join(INCLUDE, "picstep.h"), os.path.abspath(__file__)]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build_library(force=False, verbose=False):
+    """Compile csrc/picstep.hip -> csrc/libpicstep.so. Returns the library path."""
+    if not force and not needs_build():
+        return LIB
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        raise RuntimeError("hipcc not found: libpicstep.so can only be built with the ROCm toolchain")
+    cmd = [hipcc] + FLAGS + ["-o", LIB + ".tmp", SRC]
+    if verbose:
+        print(" ".join(cmd))
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("hipcc failed:\n" + r.stdout + r.stderr)
+    os.replace(LIB + ".tmp", LIB)
+    return LIB

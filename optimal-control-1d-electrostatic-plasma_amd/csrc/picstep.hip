@@ -1,0 +1,1019 @@
+// picstep.hip -- MI355X (gfx950 / CDNA4) 1-D electrostatic PIC stepper behind the C ABI of
+// include/picstep.h.  Written for wave64, LDS-resident per-block mesh tiles and coalesced SoA
+// particle streams; there is no other backend and no CPU fallback.
+//
+// One environment step = PIC.update_state of the reference (src/env/pic.py:131-146), i.e. the
+// Yoshida-4 composition of src/env/integration.py:60-75 restated as kick/drift sub-stages:
+//
+//   sweep A : q1 = x + (c1 v) dt                              deposit(q1)
+//   solve   : E = field(n) + E_ext
+//   sweep B : p1 = v + (d1 (-E(q1))) dt ; q2 = q1 + (c2 p1) dt ; deposit(q2) ; store q2,p1
+//   solve
+//   sweep C : p2 = p1 + (d2 (-E(q2))) dt ; q3 = q2 + (c3 p2) dt ; deposit(q3) ; store
+//   solve
+//   sweep D : p3 = p2 + (d3 (-E(q3))) dt ; q4 = q3 + (c4 p3) dt ; x' = mod(q4, L) ; deposit(x') ;
+//             KE partials ; store x', p3
+//   solve   : n, E_mesh (no E_ext), phi, KE, PE, PE_reward        (pic.py:145-146, util.py:119-147)
+//
+// Arithmetic inside a sub-stage keeps the reference's operand order and is compiled with
+// -ffp-contract=off so that fp64 results track NumPy to rounding (tests/ hold the bounds).
+//
+// Deposit: every workgroup owns LDS copies of its environment's mesh (one per wave, `R` copies),
+// accumulates with LDS float atomics (ds_add_f64 / ds_add_f32), then stores its partial mesh as one
+// row of a slab [env][block][Ng] with plain coalesced stores.  The field-solve kernel sums the
+// rows in block order (no global atomics, no memset between sweeps), scales to a density and
+// solves the periodic Poisson problem with two prefix scans (DESIGN.md "Field solve").
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "picstep.h"
+
+namespace {
+
+constexpr int BLOCK = 256;          // 4 waves of 64
+constexpr int WAVES = BLOCK / 64;
+
+enum Stage : int {
+  ST_A = 0,        // drift(c) from x,v ; deposit ; nothing stored
+  ST_B = 1,        // recompute q1 = x + (c_prev v) dt ; gather ; kick ; drift ; deposit ; store
+  ST_C = 2,        // gather ; kick ; drift ; deposit ; store
+  ST_D = 3,        // as C, then wrap, KE ; store wrapped x
+  ST_REFRESH = 4,  // wrap x ; deposit ; KE ; store wrapped x            (pic.py:93-112 on reset)
+  ST_PROBE = 5     // deposit positions of a scratch array, nothing stored (util.py:73-116 callers)
+};
+
+struct SweepArgs {
+  long long N;        // particles per env
+  long long ld;       // leading dimension of x, v
+  long long chunk;    // particles per workgroup (multiple of BLOCK * VEC)
+  int Ng;
+  int nblk;           // workgroups per env
+  int R;              // LDS mesh replicas per workgroup (1, 2 or 4)
+  double L, dx, dt;
+  double c_prev, c_cur, d_cur;
+};
+
+struct SolveArgs {
+  long long N;
+  int Ng;
+  int nblk;
+  double L, dx, n0;
+  double scale;        // n0 * L / N / dx, evaluated left to right as interpolate.py:18
+  double N_over_L;
+};
+
+// ---------------------------------------------------------------------------------------------
+// np.mod(np.mod(q, L), L): PIC.update_state wraps once (pic.py:139) and compute_n wraps the same
+// array again in place (util.py:51) before CIC wraps its copy (interpolate.py:6), so a value that
+// the first mod rounds up to exactly L ends as 0.  The three fast ranges are bit-identical to
+// fmod-based np.mod (Sterbenz: q-L is exact for L <= q < 2L).
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ T wrap_periodic(T q, T L) {
+  T r;
+  if (q >= T(0) && q < L) {
+    r = q;
+  } else if (q >= L && q < L + L) {
+    r = q - L;
+  } else if (q < T(0) && q >= -L) {
+    r = q + L;
+    if (r >= L) r = T(0);
+  } else {
+    r = fmod(q, L);
+    if (r < T(0)) {
+      r += L;
+      if (r >= L) r = T(0);
+    } else if (r == T(0)) {
+      r = T(0);   // np.mod returns +0 for a zero remainder
+    }
+  }
+  return r;
+}
+
+// Cell index and shape-function weights at position q.  j is the LDS index of the leftmost
+// touched node (mesh node + OFF, OFF = 1 for TSC so that node -1 has a slot).
+//   CIC (interpolate.py:6-13): jl = floor(xw/dx); wl = ((jl+1) dx - xw)/dx; wr = (xw - jl dx)/dx
+//   TSC (interpolate.py:24-34): d = (xw - jm dx)/dx; wl = .5(1.5-d)^2; wm = .75-(d-1)^2; wr = .5(d-.5)^2
+template <typename T, int SHAPE>
+__device__ __forceinline__ void locate(T q, T L, T dx, int Ng, T& xw, int& j, T (&w)[3], unsigned& bad) {
+  xw = wrap_periodic(q, L);
+  T jf = floor(xw / dx);
+  j = (int)jf;
+  if ((unsigned)j >= (unsigned)Ng) {
+    // j == Ng happens when xw/dx rounds up to Ng (undefined in the reference: bincount grows a bin and
+    // solve.py:32 raises); it is folded to node 0.  Anything else is a non-finite position.
+    if (!(j == Ng)) { bad += 1u; jf = T(0); xw = T(0); }
+    j = 0;
+  }
+  if (SHAPE == PIC_CIC) {
+    w[0] = ((jf + T(1)) * dx - xw) / dx;
+    w[1] = (xw - jf * dx) / dx;
+    w[2] = T(0);
+  } else {
+    T d = (xw - jf * dx) / dx;
+    T a = T(1.5) - d, b = d - T(1), c = d - T(0.5);
+    w[0] = T(0.5) * (a * a);
+    w[1] = T(0.75) - b * b;
+    w[2] = T(0.5) * (c * c);
+  }
+}
+
+template <typename T, int SHAPE>
+__device__ __forceinline__ T gather_field(const T* __restrict__ Es, int j, const T (&w)[3]) {
+  T e = w[0] * Es[j] + w[1] * Es[j + 1];
+  if (SHAPE == PIC_TSC) e = e + w[2] * Es[j + 2];
+  return e;
+}
+
+template <typename A, typename T, int SHAPE>
+__device__ __forceinline__ void deposit(A* __restrict__ acc, int j, const T (&w)[3]) {
+  atomicAdd(&acc[j], (A)w[0]);
+  atomicAdd(&acc[j + 1], (A)w[1]);
+  if (SHAPE == PIC_TSC) atomicAdd(&acc[j + 2], (A)w[2]);
+}
+
+template <typename T> struct VecOf;
+template <> struct VecOf<double> { using type = double2; static constexpr int n = 2; };
+template <> struct VecOf<float> { using type = float4; static constexpr int n = 4; };
+
+__device__ __forceinline__ double wave_sum(double v) {
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+  return v;
+}
+
+// One particle through one sub-stage.  Returns v*v contribution for KE (stages D / REFRESH).
+template <typename T, typename A, int SHAPE, int STAGE>
+__device__ __forceinline__ void push_one(T& xq, T& vp, const T* __restrict__ Es, A* __restrict__ acc,
+                                         T L, T dx, T dt, T c_prev, T c_cur, T d_cur, int Ng,
+                                         double& ke, unsigned& bad) {
+  T w[3];
+  T xw;
+  int j;
+  T q = xq, p = vp;
+  if (STAGE == ST_A) {
+    q = q + (c_cur * p) * dt;                                   // integration.py:42, c1
+  } else if (STAGE == ST_B || STAGE == ST_C || STAGE == ST_D) {
+    if (STAGE == ST_B) q = q + (c_prev * p) * dt;               // q1 again (sweep A stores nothing)
+    locate<T, SHAPE>(q, L, dx, Ng, xw, j, w, bad);
+    T E = gather_field<T, SHAPE>(Es, j, w);                     // util.py:105 / pic.py:120
+    p = p + (d_cur * (-E)) * dt;                                // integration.py:32, pic.py:127
+    q = q + (c_cur * p) * dt;                                   // integration.py:42
+  }
+  locate<T, SHAPE>(q, L, dx, Ng, xw, j, w, bad);
+  deposit<A, T, SHAPE>(acc, j, w);
+  if (STAGE == ST_D || STAGE == ST_REFRESH) {
+    q = xw;                                                     // pic.py:139 (+ util.py:51)
+    ke += (double)p * (double)p;
+  }
+  xq = q;
+  vp = p;
+}
+
+template <typename T, typename A, int SHAPE, int STAGE>
+__global__ __launch_bounds__(BLOCK) void sweep_kernel(T* __restrict__ x, T* __restrict__ v,
+                                                      const double* __restrict__ Ef,
+                                                      double* __restrict__ part, double* __restrict__ ke_part,
+                                                      unsigned long long* __restrict__ bad_count, SweepArgs a) {
+  constexpr int OFF = (SHAPE == PIC_TSC) ? 1 : 0;
+  constexpr int VEC = VecOf<T>::n;
+  using V = typename VecOf<T>::type;
+  constexpr bool kGather = (STAGE == ST_B || STAGE == ST_C || STAGE == ST_D);
+  constexpr bool kStore = (STAGE == ST_B || STAGE == ST_C || STAGE == ST_D || STAGE == ST_REFRESH);
+  constexpr bool kReadV = (STAGE != ST_PROBE);
+
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  const int Ng = a.Ng;
+  const int stride = Ng + 2;
+  A* acc_all = reinterpret_cast<A*>(smem_raw);
+  T* Es = reinterpret_cast<T*>(smem_raw + (size_t)a.R * stride * sizeof(A));
+  __shared__ double red[WAVES];
+
+  const int tid = threadIdx.x;
+  const int env = blockIdx.y;
+  const int blk = blockIdx.x;
+
+  for (int i = tid; i < a.R * stride; i += BLOCK) acc_all[i] = A(0);
+  if (kGather) {
+    const double* Ee = Ef + (size_t)env * Ng;
+    for (int i = tid; i < stride; i += BLOCK) {
+      int node = i - OFF;
+      node = node < 0 ? node + Ng : (node >= Ng ? node - Ng : node);
+      Es[i] = (T)Ee[node];
+    }
+  }
+  __syncthreads();
+
+  A* acc = acc_all + (size_t)((tid >> 6) & (a.R - 1)) * stride;
+  const T L = (T)a.L, dx = (T)a.dx, dt = (T)a.dt;
+  const T c_prev = (T)a.c_prev, c_cur = (T)a.c_cur, d_cur = (T)a.d_cur;
+
+  T* xe = x + (size_t)env * a.ld;
+  T* ve = v + (size_t)env * a.ld;
+  const long long begin = (long long)blk * a.chunk;
+  long long end = begin + a.chunk;
+  if (end > a.N) end = a.N;
+
+  double ke = 0.0;
+  unsigned bad = 0u;
+  for (long long i = begin + (long long)tid * VEC; i < end; i += (long long)BLOCK * VEC) {
+    if (i + VEC <= end) {
+      V xv = *reinterpret_cast<const V*>(xe + i);
+      V vv;
+      if (kReadV) vv = *reinterpret_cast<const V*>(ve + i);
+      T* xs = reinterpret_cast<T*>(&xv);
+      T* vs = reinterpret_cast<T*>(&vv);
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) {
+        T pv = kReadV ? vs[k] : T(0);
+        push_one<T, A, SHAPE, STAGE>(xs[k], pv, Es, acc, L, dx, dt, c_prev, c_cur, d_cur, Ng, ke, bad);
+        if (kReadV) vs[k] = pv;
+      }
+      if (kStore) {
+        *reinterpret_cast<V*>(xe + i) = xv;
+        if (STAGE != ST_REFRESH) *reinterpret_cast<V*>(ve + i) = vv;
+      }
+    } else {
+      for (long long k = i; k < end; ++k) {
+        T xq = xe[k];
+        T pv = kReadV ? ve[k] : T(0);
+        push_one<T, A, SHAPE, STAGE>(xq, pv, Es, acc, L, dx, dt, c_prev, c_cur, d_cur, Ng, ke, bad);
+        if (kStore) {
+          xe[k] = xq;
+          if (STAGE != ST_REFRESH) ve[k] = pv;
+        }
+      }
+    }
+  }
+  __syncthreads();
+
+  // fold the periodic ghost slots and the replicas, store this workgroup's row of the slab
+  double* row = part + ((size_t)env * a.nblk + blk) * Ng;
+  for (int c = tid; c < Ng; c += BLOCK) {
+    double s = 0.0;
+    for (int r = 0; r < a.R; ++r) {
+      const A* ar = acc_all + (size_t)r * stride;
+      double t = (double)ar[c + OFF];
+      if (SHAPE == PIC_CIC) {
+        if (c == 0) t += (double)ar[Ng];
+      } else {
+        if (c == 0) t += (double)ar[Ng + 1];
+        if (c == Ng - 1) t += (double)ar[0];
+      }
+      s += t;
+    }
+    row[c] = s;
+  }
+
+  if (STAGE == ST_D || STAGE == ST_REFRESH) {
+    double w = wave_sum(ke);
+    if ((tid & 63) == 0) red[tid >> 6] = w;
+    __syncthreads();
+    if (tid == 0) {
+      double s = 0.0;
+      for (int i = 0; i < WAVES; ++i) s += red[i];
+      ke_part[(size_t)env * a.nblk + blk] = s;
+    }
+  }
+  if (bad) atomicAdd(bad_count, (unsigned long long)bad);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Field solve (one workgroup per environment).
+// Replaces Gaussian_Elimination_Periodic + dense grad matvec (src/env/solve.py:27-53,
+// src/env/util.py:99-103, pic.py:116-117).  With G_{j+1/2} = (phi_{j+1}-phi_j)/dx the 3-point
+// periodic Poisson equation reads G_{j+1/2} - G_{j-1/2} = b_j dx, so G = cumsum(b) dx - mean and
+// E_j = -(phi_{j+1}-phi_{j-1})/(2dx) = -(G_{j+1/2} + G_{j-1/2})/2.  phi follows from a second
+// scan and is returned with zero mean.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_incl_scan(double v) {
+  const int lane = threadIdx.x & 63;
+  for (int off = 1; off < 64; off <<= 1) {
+    double t = __shfl_up(v, off);
+    if (lane >= off) v += t;
+  }
+  return v;
+}
+
+__device__ __forceinline__ double block_excl_scan(double v, double* ws, double& total) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  double inc = wave_incl_scan(v);
+  if (lane == 63) ws[w] = inc;
+  __syncthreads();
+  double off = 0.0, tot = 0.0;
+  for (int i = 0; i < WAVES; ++i) {
+    double s = ws[i];
+    if (i < w) off += s;
+    tot += s;
+  }
+  __syncthreads();
+  total = tot;
+  return off + (inc - v);
+}
+
+__device__ __forceinline__ double block_sum(double v, double* ws) {
+  double w = wave_sum(v);
+  if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = w;
+  __syncthreads();
+  double s = 0.0;
+  for (int i = 0; i < WAVES; ++i) s += ws[i];
+  __syncthreads();
+  return s;
+}
+
+__global__ __launch_bounds__(BLOCK) void field_solve_kernel(
+    const double* __restrict__ part, const double* __restrict__ E_ext, const double* __restrict__ ke_part,
+    double* __restrict__ n_out, double* __restrict__ Ef_out, double* __restrict__ E_out,
+    double* __restrict__ phi_out, double* __restrict__ KE_out, double* __restrict__ PE_out,
+    double* __restrict__ PEr_out, SolveArgs a) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  double* sb = reinterpret_cast<double*>(smem_raw);   // b, then G_{j+1/2}
+  double* se = sb + a.Ng;                             // E, then phi
+  __shared__ double ws[WAVES];
+
+  const int tid = threadIdx.x;
+  const int env = blockIdx.x;
+  const int Ng = a.Ng;
+  const int m = (Ng + BLOCK - 1) / BLOCK;
+  const int lo = min(tid * m, Ng), hi = min(lo + m, Ng);
+
+  // density: sum the slab rows in block order, scale (interpolate.py:16-18), b = n - n0 (pic.py:116)
+  const double* slab = part + (size_t)env * a.nblk * Ng;
+  for (int j = tid; j < Ng; j += BLOCK) {
+    double s = 0.0;
+    for (int b = 0; b < a.nblk; ++b) s += slab[(size_t)b * Ng + j];
+    double nj = s * a.scale;
+    if (n_out) n_out[(size_t)env * Ng + j] = nj;
+    sb[j] = nj - a.n0;
+  }
+  __syncthreads();
+
+  // G_{j+1/2} = dx * inclusive_scan(b)
+  double loc = 0.0;
+  for (int j = lo; j < hi; ++j) loc += sb[j];
+  double tot;
+  double run = block_excl_scan(loc, ws, tot);
+  loc = 0.0;
+  for (int j = lo; j < hi; ++j) {
+    run += sb[j];
+    double g = run * a.dx;
+    sb[j] = g;
+    loc += g;
+  }
+  const double gmean = block_sum(loc, ws) / (double)Ng;   // syncs: all of sb is G now
+
+  // E_j = -(G_{j+1/2} + G_{j-1/2}) / 2, plus the external field for force evaluations (util.py:102-103)
+  double e2 = 0.0;
+  for (int j = tid; j < Ng; j += BLOCK) {
+    double g = sb[j] - gmean;
+    double gm = sb[j == 0 ? Ng - 1 : j - 1] - gmean;
+    double E = -0.5 * (g + gm);
+    se[j] = E;
+    double Et = E_ext ? E + E_ext[(size_t)env * Ng + j] : E;
+    if (Ef_out) Ef_out[(size_t)env * Ng + j] = Et;
+    if (E_out) E_out[(size_t)env * Ng + j] = Et;
+    e2 += Et * Et;
+  }
+  const double S = block_sum(e2, ws);
+  if (tid == 0) {
+    double pe = 0.5 * S * a.dx;                       // objective.py:33 / util.py:129
+    if (PEr_out) PEr_out[env] = pe;
+    if (PE_out) PE_out[env] = pe * a.N_over_L;        // util.py:130
+  }
+
+  if (KE_out) {
+    double k = 0.0;
+    for (int b = tid; b < a.nblk; b += BLOCK) k += ke_part[(size_t)env * a.nblk + b];
+    k = block_sum(k, ws);
+    if (tid == 0) KE_out[env] = 0.5 * k;              // util.py:144
+  }
+
+  if (phi_out) {
+    // phi_{j+1} = phi_j + dx G_{j+1/2}: exclusive scan, then remove the mean
+    loc = 0.0;
+    for (int j = lo; j < hi; ++j) loc += (sb[j] - gmean) * a.dx;
+    run = block_excl_scan(loc, ws, tot);
+    double ploc = 0.0;
+    for (int j = lo; j < hi; ++j) {
+      se[j] = run;
+      ploc += run;
+      run += (sb[j] - gmean) * a.dx;
+    }
+    const double pmean = block_sum(ploc, ws) / (double)Ng;
+    for (int j = tid; j < Ng; j += BLOCK) phi_out[(size_t)env * Ng + j] = se[j] - pmean;
+  }
+}
+
+// PIC.E (pic.py:120) and the CIC bookkeeping attributes (pic.py:104-107), on demand.
+template <typename T, int SHAPE>
+__global__ __launch_bounds__(BLOCK) void gather_E_kernel(const T* __restrict__ x, const double* __restrict__ E_mesh,
+                                                         T* __restrict__ E_out, long long N, long long ld, int Ng,
+                                                         double Ld, double dxd) {
+  constexpr int OFF = (SHAPE == PIC_TSC) ? 1 : 0;
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  T* Es = reinterpret_cast<T*>(smem_raw);
+  const int env = blockIdx.y;
+  for (int i = threadIdx.x; i < Ng + 2; i += BLOCK) {
+    int node = i - OFF;
+    node = node < 0 ? node + Ng : (node >= Ng ? node - Ng : node);
+    Es[i] = (T)E_mesh[(size_t)env * Ng + node];
+  }
+  __syncthreads();
+  const T L = (T)Ld, dx = (T)dxd;
+  for (long long i = (long long)blockIdx.x * BLOCK + threadIdx.x; i < N; i += (long long)gridDim.x * BLOCK) {
+    T w[3], xw;
+    int j;
+    unsigned bad = 0;
+    locate<T, SHAPE>(x[(size_t)env * ld + i], L, dx, Ng, xw, j, w, bad);
+    E_out[(size_t)env * N + i] = gather_field<T, SHAPE>(Es, j, w);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void cic_query_kernel(const T* __restrict__ x, long long N, int Ng, double Ld,
+                                                          double dxd, long long* __restrict__ jl,
+                                                          long long* __restrict__ jr, double* __restrict__ wl,
+                                                          double* __restrict__ wr) {
+  const T L = (T)Ld, dx = (T)dxd;
+  for (long long i = (long long)blockIdx.x * BLOCK + threadIdx.x; i < N; i += (long long)gridDim.x * BLOCK) {
+    T w[3], xw;
+    int j;
+    unsigned bad = 0;
+    locate<T, PIC_CIC>(x[i], L, dx, Ng, xw, j, w, bad);
+    if (jl) jl[i] = j;
+    if (jr) jr[i] = (j + 1 == Ng) ? 0 : j + 1;
+    if (wl) wl[i] = (double)w[0];
+    if (wr) wr[i] = (double)w[1];
+  }
+}
+
+// dense [env][N] <-> padded [env][ld]
+template <typename T>
+__global__ void repack_kernel(T* __restrict__ dst, const T* __restrict__ src, long long N, long long ld_dst,
+                              long long ld_src) {
+  const int env = blockIdx.y;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (long long)gridDim.x * blockDim.x)
+    dst[(size_t)env * ld_dst + i] = src[(size_t)env * ld_src + i];
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+// Host side
+// ---------------------------------------------------------------------------------------------
+struct pic_handle {
+  pic_config cfg{};
+  int vec = 2;
+  size_t esz = 8;          // particle element size
+  size_t asz = 8;          // LDS accumulator element size
+  long long ld = 0;
+  long long chunk = 0;
+  int nblk = 0;
+  int R = 1;
+  size_t sweep_lds = 0, solve_lds = 0;
+  double dx = 0, scale = 0;
+  double cs[4]{}, ds[4]{};
+  hipStream_t stream = nullptr;
+  void* x = nullptr;
+  void* v = nullptr;
+  void* scratch = nullptr;        // [env][ld] staging (eval_field positions, dense<->padded copies)
+  double* part = nullptr;         // [env][nblk][Ng]
+  double* ke_part = nullptr;      // [env][nblk]
+  double* Ef = nullptr;           // field used by the gathers (E + E_ext)
+  double* n = nullptr;
+  double* E_mesh = nullptr;
+  double* phi = nullptr;
+  double* ext = nullptr;          // device copy of a host E_ext
+  double* aux_n = nullptr;        // eval_field outputs
+  double* aux_E = nullptr;
+  double* aux_pe = nullptr;
+  double* KE = nullptr;
+  double* PE = nullptr;
+  double* PEr = nullptr;
+  unsigned long long* bad = nullptr;
+  bool has_state = false;
+  // profiling
+  bool prof = false;
+  std::vector<hipEvent_t> ev;     // pairs
+  std::vector<int> ev_kind;
+  double ms_sum[8]{};
+  int64_t launches[8]{};
+  std::string err;
+};
+
+namespace {
+
+thread_local std::string g_create_error;
+
+#define HIPCHK(h, call)                                                                       \
+  do {                                                                                        \
+    hipError_t e_ = (call);                                                                   \
+    if (e_ != hipSuccess) {                                                                   \
+      (h)->err = std::string(#call) + ": " + hipGetErrorString(e_);                           \
+      return PIC_EHIP;                                                                        \
+    }                                                                                         \
+  } while (0)
+
+int fail(pic_handle* h, int code, const std::string& msg) {
+  if (h) h->err = msg; else g_create_error = msg;
+  return code;
+}
+
+void yoshida_coefficients(double (&c)[4], double (&d)[4]) {
+  // integration.py:62-69, same expressions in the same order
+  const double cbrt2 = std::pow(2.0, 1.0 / 3.0);
+  const double w0 = (-1) * cbrt2 / (2 - cbrt2);
+  const double w1 = 1 / (2 - cbrt2);
+  c[0] = c[3] = 0.5 * w1;
+  c[1] = c[2] = 0.5 * (w0 + w1);
+  d[0] = 0.0;
+  d[1] = d[3] = w1;
+  d[2] = w0;
+}
+
+template <typename T, typename A, int SHAPE, int STAGE>
+void launch_sweep_t(pic_handle* h, void* x, void* v, const SweepArgs& a) {
+  dim3 grid(h->nblk, h->cfg.num_envs);
+  hipLaunchKernelGGL((sweep_kernel<T, A, SHAPE, STAGE>), grid, dim3(BLOCK), h->sweep_lds, h->stream,
+                     static_cast<T*>(x), static_cast<T*>(v), h->Ef, h->part, h->ke_part, h->bad, a);
+}
+
+template <typename T, typename A, int SHAPE>
+void launch_sweep_s(pic_handle* h, int stage, void* x, void* v, const SweepArgs& a) {
+  switch (stage) {
+    case ST_A: launch_sweep_t<T, A, SHAPE, ST_A>(h, x, v, a); break;
+    case ST_B: launch_sweep_t<T, A, SHAPE, ST_B>(h, x, v, a); break;
+    case ST_C: launch_sweep_t<T, A, SHAPE, ST_C>(h, x, v, a); break;
+    case ST_D: launch_sweep_t<T, A, SHAPE, ST_D>(h, x, v, a); break;
+    case ST_REFRESH: launch_sweep_t<T, A, SHAPE, ST_REFRESH>(h, x, v, a); break;
+    default: launch_sweep_t<T, A, SHAPE, ST_PROBE>(h, x, v, a); break;
+  }
+}
+
+template <typename T, typename A>
+void launch_sweep_i(pic_handle* h, int stage, void* x, void* v, const SweepArgs& a) {
+  if (h->cfg.interpol == PIC_TSC) launch_sweep_s<T, A, PIC_TSC>(h, stage, x, v, a);
+  else launch_sweep_s<T, A, PIC_CIC>(h, stage, x, v, a);
+}
+
+void prof_begin(pic_handle* h, int kind) {
+  if (!h->prof) return;
+  hipEvent_t a, b;
+  hipEventCreate(&a);
+  hipEventCreate(&b);
+  hipEventRecord(a, h->stream);
+  h->ev.push_back(a);
+  h->ev.push_back(b);
+  h->ev_kind.push_back(kind);
+}
+void prof_end(pic_handle* h) {
+  if (!h->prof) return;
+  hipEventRecord(h->ev.back(), h->stream);
+}
+void prof_drain(pic_handle* h) {
+  for (size_t i = 0; i < h->ev_kind.size(); ++i) {
+    float ms = 0.f;
+    hipEventSynchronize(h->ev[2 * i + 1]);
+    if (hipEventElapsedTime(&ms, h->ev[2 * i], h->ev[2 * i + 1]) == hipSuccess) {
+      h->ms_sum[h->ev_kind[i]] += ms;
+      h->launches[h->ev_kind[i]] += 1;
+    }
+    hipEventDestroy(h->ev[2 * i]);
+    hipEventDestroy(h->ev[2 * i + 1]);
+  }
+  h->ev.clear();
+  h->ev_kind.clear();
+}
+
+void launch_sweep(pic_handle* h, int stage, void* x, void* v, double c_prev, double c_cur, double d_cur) {
+  SweepArgs a;
+  a.N = h->cfg.N; a.ld = h->ld; a.chunk = h->chunk; a.Ng = h->cfg.Ng; a.nblk = h->nblk; a.R = h->R;
+  a.L = h->cfg.L; a.dx = h->dx; a.dt = h->cfg.dt;
+  a.c_prev = c_prev; a.c_cur = c_cur; a.d_cur = d_cur;
+  prof_begin(h, stage <= ST_D ? stage : 5);
+  if (h->cfg.particle_dtype == PIC_F64) launch_sweep_i<double, double>(h, stage, x, v, a);
+  else if (h->cfg.accum_dtype == PIC_F64) launch_sweep_i<float, double>(h, stage, x, v, a);
+  else launch_sweep_i<float, float>(h, stage, x, v, a);
+  prof_end(h);
+}
+
+struct SolveOut {
+  const double* ext = nullptr;
+  const double* ke_part = nullptr;
+  double* n = nullptr; double* Ef = nullptr; double* E = nullptr; double* phi = nullptr;
+  double* KE = nullptr; double* PE = nullptr; double* PEr = nullptr;
+};
+
+void launch_solve(pic_handle* h, const SolveOut& o) {
+  SolveArgs a;
+  a.N = h->cfg.N; a.Ng = h->cfg.Ng; a.nblk = h->nblk; a.L = h->cfg.L; a.dx = h->dx; a.n0 = h->cfg.n0;
+  a.scale = h->scale; a.N_over_L = (double)h->cfg.N / h->cfg.L;
+  prof_begin(h, 4);
+  hipLaunchKernelGGL(field_solve_kernel, dim3(h->cfg.num_envs), dim3(BLOCK), h->solve_lds, h->stream, h->part, o.ext,
+                     o.ke_part, o.n, o.Ef, o.E, o.phi, o.KE, o.PE, o.PEr, a);
+  prof_end(h);
+}
+
+int refresh_fields(pic_handle* h) {
+  launch_sweep(h, ST_REFRESH, h->x, h->v, 0, 0, 0);
+  SolveOut o;
+  o.ke_part = h->ke_part; o.n = h->n; o.Ef = h->Ef; o.E = h->E_mesh; o.phi = h->phi;
+  o.KE = h->KE; o.PE = h->PE; o.PEr = h->PEr;
+  launch_solve(h, o);
+  HIPCHK(h, hipGetLastError());
+  return PIC_OK;
+}
+
+// copy a dense [env][N] caller array into a padded [env][ld] device array
+int upload(pic_handle* h, void* dst_padded, const void* src, int mem_kind) {
+  const size_t row = (size_t)h->cfg.N * h->esz;
+  if (mem_kind == PIC_HOST) {
+    HIPCHK(h, hipMemcpy2DAsync(dst_padded, (size_t)h->ld * h->esz, src, row, row, h->cfg.num_envs,
+                               hipMemcpyHostToDevice, h->stream));
+  } else {
+    HIPCHK(h, hipMemcpy2DAsync(dst_padded, (size_t)h->ld * h->esz, src, row, row, h->cfg.num_envs,
+                               hipMemcpyDeviceToDevice, h->stream));
+  }
+  return PIC_OK;
+}
+
+int download(pic_handle* h, void* dst, const void* src_padded, int mem_kind) {
+  const size_t row = (size_t)h->cfg.N * h->esz;
+  HIPCHK(h, hipMemcpy2DAsync(dst, row, src_padded, (size_t)h->ld * h->esz, row, h->cfg.num_envs,
+                             mem_kind == PIC_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, h->stream));
+  return PIC_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int pic_abi_version(void) { return PICSTEP_ABI_VERSION; }
+
+const char* pic_last_error(pic_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int pic_create(const pic_config* cfg, pic_handle** out) {
+  if (!cfg || !out) return fail(nullptr, PIC_EINVAL, "pic_create: null argument");
+  *out = nullptr;
+  if (cfg->N < 1 || cfg->Ng < 4 || cfg->num_envs < 1 || !(cfg->L > 0) || !(cfg->dt > 0) || !(cfg->n0 > 0))
+    return fail(nullptr, PIC_EINVAL, "pic_create: need N>=1, Ng>=4, num_envs>=1, L>0, dt>0, n0>0");
+  if (cfg->num_envs > 65535) return fail(nullptr, PIC_EINVAL, "pic_create: num_envs > 65535");
+  if (cfg->particle_dtype != PIC_F64 && cfg->particle_dtype != PIC_F32)
+    return fail(nullptr, PIC_EINVAL, "pic_create: particle_dtype must be PIC_F64 or PIC_F32");
+  if (cfg->accum_dtype != PIC_F64 && cfg->accum_dtype != PIC_F32)
+    return fail(nullptr, PIC_EINVAL, "pic_create: accum_dtype must be PIC_F64 or PIC_F32");
+  if (cfg->accum_dtype == PIC_F32 && cfg->particle_dtype != PIC_F32)
+    return fail(nullptr, PIC_EINVAL, "pic_create: a float32 accumulator needs float32 particles");
+  if (cfg->interpol != PIC_CIC && cfg->interpol != PIC_TSC)
+    return fail(nullptr, PIC_EINVAL, "pic_create: interpol must be PIC_CIC or PIC_TSC");
+
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+    return fail(nullptr, PIC_EHIP, "pic_create: no HIP device visible (this library has no CPU path)");
+  if (cfg->device_id < 0 || cfg->device_id >= ndev) return fail(nullptr, PIC_EINVAL, "pic_create: bad device_id");
+
+  pic_handle* h = new (std::nothrow) pic_handle();
+  if (!h) return fail(nullptr, PIC_ENOMEM, "pic_create: out of host memory");
+  h->cfg = *cfg;
+  h->esz = cfg->particle_dtype == PIC_F64 ? 8 : 4;
+  h->asz = cfg->accum_dtype == PIC_F64 ? 8 : 4;
+  h->vec = cfg->particle_dtype == PIC_F64 ? 2 : 4;
+  h->dx = cfg->L / cfg->Ng;                                   // pic.py:36
+  h->scale = cfg->n0 * cfg->L / (double)cfg->N / h->dx;       // interpolate.py:18
+  yoshida_coefficients(h->cs, h->ds);
+  h->ld = (cfg->N + 63) / 64 * 64;
+
+  // workgroups per environment: enough in total to fill 256 CUs several times, at least one
+  // BLOCK*VEC tile each
+  const long long tile = (long long)BLOCK * h->vec;
+  long long nblk = cfg->blocks_per_env;
+  if (nblk <= 0) {
+    const long long target_total = 4096;
+    nblk = (target_total + cfg->num_envs - 1) / cfg->num_envs;
+    const long long max_by_work = (cfg->N + 8 * tile - 1) / (8 * tile);   // >= 8 tiles per workgroup
+    if (nblk > max_by_work) nblk = max_by_work;
+    if (nblk < 1) nblk = 1;
+  }
+  long long chunk = (cfg->N + nblk - 1) / nblk;
+  chunk = (chunk + tile - 1) / tile * tile;
+  nblk = (cfg->N + chunk - 1) / chunk;
+  if (nblk > 65535) { delete h; return fail(nullptr, PIC_EINVAL, "pic_create: blocks_per_env too large"); }
+  h->chunk = chunk;
+  h->nblk = (int)nblk;
+
+  const size_t stride = (size_t)cfg->Ng + 2;
+  h->R = 4;
+  while (h->R > 1 && h->R * stride * h->asz + stride * h->esz > 40 * 1024) h->R >>= 1;
+  h->sweep_lds = h->R * stride * h->asz + stride * h->esz;
+  h->solve_lds = 2 * (size_t)cfg->Ng * sizeof(double);
+  if (h->sweep_lds > 150 * 1024 || h->solve_lds > 150 * 1024) {
+    delete h;
+    return fail(nullptr, PIC_EINVAL, "pic_create: Ng too large for the LDS-resident mesh (max ~9000 cells)");
+  }
+
+#define CREATE_CHK(call)                                                                      \
+  do {                                                                                        \
+    hipError_t e_ = (call);                                                                   \
+    if (e_ != hipSuccess) {                                                                   \
+      std::string m = std::string("pic_create: " #call ": ") + hipGetErrorString(e_);         \
+      pic_destroy(h);                                                                         \
+      return fail(nullptr, e_ == hipErrorOutOfMemory ? PIC_ENOMEM : PIC_EHIP, m);            \
+    }                                                                                         \
+  } while (0)
+
+  CREATE_CHK(hipSetDevice(cfg->device_id));
+  CREATE_CHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+  const size_t pbytes = (size_t)cfg->num_envs * h->ld * h->esz;
+  const size_t gbytes = (size_t)cfg->num_envs * cfg->Ng * sizeof(double);
+  CREATE_CHK(hipMalloc(&h->x, pbytes));
+  CREATE_CHK(hipMalloc(&h->v, pbytes));
+  CREATE_CHK(hipMemsetAsync(h->x, 0, pbytes, h->stream));
+  CREATE_CHK(hipMemsetAsync(h->v, 0, pbytes, h->stream));
+  CREATE_CHK(hipMalloc((void**)&h->part, gbytes * h->nblk));
+  CREATE_CHK(hipMalloc((void**)&h->ke_part, (size_t)cfg->num_envs * h->nblk * sizeof(double)));
+  CREATE_CHK(hipMemsetAsync(h->ke_part, 0, (size_t)cfg->num_envs * h->nblk * sizeof(double), h->stream));
+  double** grids[] = {&h->Ef, &h->n, &h->E_mesh, &h->phi, &h->ext, &h->aux_n, &h->aux_E};
+  for (double** g : grids) {
+    CREATE_CHK(hipMalloc((void**)g, gbytes));
+    CREATE_CHK(hipMemsetAsync(*g, 0, gbytes, h->stream));
+  }
+  double** scal[] = {&h->KE, &h->PE, &h->PEr, &h->aux_pe};
+  for (double** s : scal) {
+    CREATE_CHK(hipMalloc((void**)s, (size_t)cfg->num_envs * sizeof(double)));
+    CREATE_CHK(hipMemsetAsync(*s, 0, (size_t)cfg->num_envs * sizeof(double), h->stream));
+  }
+  CREATE_CHK(hipMalloc((void**)&h->bad, sizeof(unsigned long long)));
+  CREATE_CHK(hipMemsetAsync(h->bad, 0, sizeof(unsigned long long), h->stream));
+  CREATE_CHK(hipStreamSynchronize(h->stream));
+#undef CREATE_CHK
+  *out = h;
+  return PIC_OK;
+}
+
+int pic_destroy(pic_handle* h) {
+  if (!h) return PIC_OK;
+  hipSetDevice(h->cfg.device_id);
+  if (h->stream) hipStreamSynchronize(h->stream);
+  prof_drain(h);
+  void* bufs[] = {h->x, h->v, h->scratch, h->part, h->ke_part, h->Ef, h->n, h->E_mesh, h->phi, h->ext,
+                  h->aux_n, h->aux_E, h->aux_pe, h->KE, h->PE, h->PEr, h->bad};
+  for (void* b : bufs)
+    if (b) hipFree(b);
+  if (h->stream) hipStreamDestroy(h->stream);
+  delete h;
+  return PIC_OK;
+}
+
+int pic_sync(pic_handle* h) {
+  if (!h) return PIC_EINVAL;
+  HIPCHK(h, hipSetDevice(h->cfg.device_id));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return PIC_OK;
+}
+
+int pic_set_particles(pic_handle* h, const void* x, const void* v, int mem_kind) {
+  if (!h || !x || !v) return fail(h, PIC_EINVAL, "pic_set_particles: null argument");
+  HIPCHK(h, hipSetDevice(h->cfg.device_id));
+  int rc = upload(h, h->x, x, mem_kind);
+  if (rc) return rc;
+  rc = upload(h, h->v, v, mem_kind);
+  if (rc) return rc;
+  if (mem_kind == PIC_HOST) HIPCHK(h, hipStreamSynchronize(h->stream));
+  h->has_state = true;
+  return PIC_OK;
+}
+
+int pic_refresh(pic_handle* h) {
+  if (!h) return PIC_EINVAL;
+  if (!h->has_state) return fail(h, PIC_ESTATE, "pic_refresh: no particles loaded (call pic_reset first)");
+  HIPCHK(h, hipSetDevice(h->cfg.device_id));
+  return refresh_fields(h);
+}
+
+int pic_reset(pic_handle* h, const void* x0, const void* v0, int mem_kind) {
+  int rc = pic_set_particles(h, x0, v0, mem_kind);
+  if (rc) return rc;
+  HIPCHK(h, hipMemsetAsync(h->bad, 0, sizeof(unsigned long long), h->stream));
+  return refresh_fields(h);
+}
+
+int pic_step(pic_handle* h, const double* E_ext, int mem_kind, int nsteps) {
+  if (!h) return PIC_EINVAL;
+  if (!h->has_state) return fail(h, PIC_ESTATE, "pic_step: call pic_reset first");
+  if (nsteps < 0) return fail(h, PIC_EINVAL, "pic_step: nsteps < 0");
+  HIPCHK(h, hipSetDevice(h->cfg.device_id));
+  const double* ext = nullptr;
+  if (E_ext) {
+    if (mem_kind == PIC_HOST) {
+      HIPCHK(h, hipMemcpyAsync(h->ext, E_ext, (size_t)h->cfg.num_envs * h->cfg.Ng * sizeof(double),
+                               hipMemcpyHostToDevice, h->stream));
+      ext = h->ext;
+    } else {
+      ext = E_ext;
+    }
+  }
+  const double* c = h->cs;
+  const double* d = h->ds;
+  for (int s = 0; s < nsteps; ++s) {
+    SolveOut f;           // force evaluation: only the gather field is needed
+    f.ext = ext; f.Ef = h->Ef;
+    launch_sweep(h, ST_A, h->x, h->v, 0.0, c[0], 0.0);
+    launch_solve(h, f);
+    launch_sweep(h, ST_B, h->x, h->v, c[0], c[1], d[1]);
+    launch_solve(h, f);
+    launch_sweep(h, ST_C, h->x, h->v, 0.0, c[2], d[2]);
+    launch_solve(h, f);
+    launch_sweep(h, ST_D, h->x, h->v, 0.0, c[3], d[3]);
+    SolveOut o;           // post-step refresh: no external field (pic.py:114-117)
+    o.ke_part = h->ke_part; o.n = h->n; o.E = h->E_mesh; o.phi = h->phi;
+    o.KE = h->KE; o.PE = h->PE; o.PEr = h->PEr;
+    launch_solve(h, o);
+  }
+  HIPCHK(h, hipGetLastError());
+  return PIC_OK;
+}
+
+int pic_get_particles(pic_handle* h, void* x, void* v, int mem_kind) {
+  if (!h) return PIC_EINVAL;
+  HIPCHK(h, hipSetDevice(h->cfg.device_id));
+  int rc = PIC_OK;
+  if (x) rc = download(h, x, h->x, mem_kind);
+  if (!rc && v) rc = download(h, v, h->v, mem_kind);
+  if (rc) return rc;
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return PIC_OK;
+}
+
+int pic_device_ptrs(pic_handle* h, void** x, void** v, int64_t* ld, double** n, double** E_mesh, double** phi,
+                    double** KE, double** PE, double** PE_reward) {
+  if (!h) return PIC_EINVAL;
+  if (x) *x = h->x;
+  if (v) *v = h->v;
+  if (ld) *ld = h->ld;
+  if (n) *n = h->n;
+  if (E_mesh) *E_mesh = h->E_mesh;
+  if (phi) *phi = h->phi;
+  if (KE) *KE = h->KE;
+  if (PE) *PE = h->PE;
+  if (PE_reward) *PE_reward = h->PEr;
+  return PIC_OK;
+}
+
+int pic_get_fields(pic_handle* h, double* n, double* E_mesh, double* phi) {
+  if (!h) return PIC_EINVAL;
+  HIPCHK(h, hipSetDevice(h->cfg.device_id));
+  const size_t gbytes = (size_t)h->cfg.num_envs * h->cfg.Ng * sizeof(double);
+  if (n) HIPCHK(h, hipMemcpyAsync(n, h->n, gbytes, hipMemcpyDeviceToHost, h->stream));
+  if (E_mesh) HIPCHK(h, hipMemcpyAsync(E_mesh, h->E_mesh, gbytes, hipMemcpyDeviceToHost, h->stream));
+  if (phi) HIPCHK(h, hipMemcpyAsync(phi, h->phi, gbytes, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return PIC_OK;
+}
+
+int pic_get_energies(pic_handle* h, double* KE, double* PE, double* PE_reward) {
+  if (!h) return PIC_EINVAL;
+  HIPCHK(h, hipSetDevice(h->cfg.device_id));
+  const size_t b = (size_t)h->cfg.num_envs * sizeof(double);
+  if (KE) HIPCHK(h, hipMemcpyAsync(KE, h->KE, b, hipMemcpyDeviceToHost, h->stream));
+  if (PE) HIPCHK(h, hipMemcpyAsync(PE, h->PE, b, hipMemcpyDeviceToHost, h->stream));
+  if (PE_reward) HIPCHK(h, hipMemcpyAsync(PE_reward, h->PEr, b, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return PIC_OK;
+}
+
+static int ensure_scratch(pic_handle* h) {
+  if (h->scratch) return PIC_OK;
+  const size_t pbytes = (size_t)h->cfg.num_envs * h->ld * h->esz;
+  HIPCHK(h, hipMalloc(&h->scratch, pbytes));
+  HIPCHK(h, hipMemsetAsync(h->scratch, 0, pbytes, h->stream));
+  return PIC_OK;
+}
+
+int pic_gather_E(pic_handle* h, void* E_particles, int mem_kind) {
+  if (!h || !E_particles) return fail(h, PIC_EINVAL, "pic_gather_E: null argument");
+  if (!h->has_state) return fail(h, PIC_ESTATE, "pic_gather_E: call pic_reset first");
+  HIPCHK(h, hipSetDevice(h->cfg.device_id));
+  void* dst = E_particles;
+  if (mem_kind == PIC_HOST) {
+    int rc = ensure_scratch(h);
+    if (rc) return rc;
+    dst = h->scratch;     // dense [env][N] fits in [env][ld]
+  }
+  long long gx = (h->cfg.N + BLOCK - 1) / BLOCK;
+  if (gx > 1024) gx = 1024;
+  dim3 grid((unsigned)gx, h->cfg.num_envs);
+  const size_t lds = ((size_t)h->cfg.Ng + 2) * h->esz;
+  const bool tsc = h->cfg.interpol == PIC_TSC;
+  if (h->cfg.particle_dtype == PIC_F64) {
+    if (tsc) hipLaunchKernelGGL((gather_E_kernel<double, PIC_TSC>), grid, dim3(BLOCK), lds, h->stream, (const double*)h->x, h->E_mesh, (double*)dst, h->cfg.N, h->ld, h->cfg.Ng, h->cfg.L, h->dx);
+    else hipLaunchKernelGGL((gather_E_kernel<double, PIC_CIC>), grid, dim3(BLOCK), lds, h->stream, (const double*)h->x, h->E_mesh, (double*)dst, h->cfg.N, h->ld, h->cfg.Ng, h->cfg.L, h->dx);
+  } else {
+    if (tsc) hipLaunchKernelGGL((gather_E_kernel<float, PIC_TSC>), grid, dim3(BLOCK), lds, h->stream, (const float*)h->x, h->E_mesh, (float*)dst, h->cfg.N, h->ld, h->cfg.Ng, h->cfg.L, h->dx);
+    else hipLaunchKernelGGL((gather_E_kernel<float, PIC_CIC>), grid, dim3(BLOCK), lds, h->stream, (const float*)h->x, h->E_mesh, (float*)dst, h->cfg.N, h->ld, h->cfg.Ng, h->cfg.L, h->dx);
+  }
+  HIPCHK(h, hipGetLastError());
+  if (mem_kind == PIC_HOST)
+    HIPCHK(h, hipMemcpyAsync(E_particles, dst, (size_t)h->cfg.num_envs * h->cfg.N * h->esz, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return PIC_OK;
+}
+
+int pic_get_cic(pic_handle* h, int env, int64_t* indx_l, int64_t* indx_r, double* weight_l, double* weight_r) {
+  if (!h) return PIC_EINVAL;
+  if (env < 0 || env >= h->cfg.num_envs) return fail(h, PIC_EINVAL, "pic_get_cic: env out of range");
+  if (!h->has_state) return fail(h, PIC_ESTATE, "pic_get_cic: call pic_reset first");
+  HIPCHK(h, hipSetDevice(h->cfg.device_id));
+  const long long N = h->cfg.N;
+  long long* dj = nullptr;
+  double* dw = nullptr;
+  HIPCHK(h, hipMalloc((void**)&dj, 2 * N * sizeof(long long)));
+  if (hipMalloc((void**)&dw, 2 * N * sizeof(double)) != hipSuccess) { hipFree(dj); return fail(h, PIC_ENOMEM, "pic_get_cic: hipMalloc"); }
+  long long gx = (N + BLOCK - 1) / BLOCK;
+  if (gx > 1024) gx = 1024;
+  const char* xe = (const char*)h->x + (size_t)env * h->ld * h->esz;
+  if (h->cfg.particle_dtype == PIC_F64)
+    hipLaunchKernelGGL(cic_query_kernel<double>, dim3((unsigned)gx), dim3(BLOCK), 0, h->stream, (const double*)xe, N, h->cfg.Ng, h->cfg.L, h->dx, dj, dj + N, dw, dw + N);
+  else
+    hipLaunchKernelGGL(cic_query_kernel<float>, dim3((unsigned)gx), dim3(BLOCK), 0, h->stream, (const float*)xe, N, h->cfg.Ng, h->cfg.L, h->dx, dj, dj + N, dw, dw + N);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess && indx_l) e = hipMemcpyAsync(indx_l, dj, N * sizeof(long long), hipMemcpyDeviceToHost, h->stream);
+  if (e == hipSuccess && indx_r) e = hipMemcpyAsync(indx_r, dj + N, N * sizeof(long long), hipMemcpyDeviceToHost, h->stream);
+  if (e == hipSuccess && weight_l) e = hipMemcpyAsync(weight_l, dw, N * sizeof(double), hipMemcpyDeviceToHost, h->stream);
+  if (e == hipSuccess && weight_r) e = hipMemcpyAsync(weight_r, dw + N, N * sizeof(double), hipMemcpyDeviceToHost, h->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+  hipFree(dj);
+  hipFree(dw);
+  if (e != hipSuccess) return fail(h, PIC_EHIP, std::string("pic_get_cic: ") + hipGetErrorString(e));
+  return PIC_OK;
+}
+
+int pic_eval_field(pic_handle* h, const void* x, int mem_kind, const double* E_ext, double* n, double* E_mesh,
+                   double* half_sum_E2_dx) {
+  if (!h || !x) return fail(h, PIC_EINVAL, "pic_eval_field: null argument");
+  HIPCHK(h, hipSetDevice(h->cfg.device_id));
+  int rc = ensure_scratch(h);
+  if (rc) return rc;
+  rc = upload(h, h->scratch, x, mem_kind);
+  if (rc) return rc;
+  const size_t gbytes = (size_t)h->cfg.num_envs * h->cfg.Ng * sizeof(double);
+  const double* ext = nullptr;
+  if (E_ext) {
+    HIPCHK(h, hipMemcpyAsync(h->ext, E_ext, gbytes, hipMemcpyHostToDevice, h->stream));
+    ext = h->ext;
+  }
+  launch_sweep(h, ST_PROBE, h->scratch, h->scratch, 0, 0, 0);
+  SolveOut o;
+  o.ext = ext; o.n = h->aux_n; o.E = h->aux_E; o.PEr = h->aux_pe;
+  launch_solve(h, o);
+  HIPCHK(h, hipGetLastError());
+  if (n) HIPCHK(h, hipMemcpyAsync(n, h->aux_n, gbytes, hipMemcpyDeviceToHost, h->stream));
+  if (E_mesh) HIPCHK(h, hipMemcpyAsync(E_mesh, h->aux_E, gbytes, hipMemcpyDeviceToHost, h->stream));
+  if (half_sum_E2_dx)
+    HIPCHK(h, hipMemcpyAsync(half_sum_E2_dx, h->aux_pe, (size_t)h->cfg.num_envs * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return PIC_OK;
+}
+
+int pic_profile(pic_handle* h, int enable) {
+  if (!h) return PIC_EINVAL;
+  HIPCHK(h, hipSetDevice(h->cfg.device_id));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  prof_drain(h);
+  h->prof = enable != 0;
+  if (enable) {
+    std::memset(h->ms_sum, 0, sizeof(h->ms_sum));
+    std::memset(h->launches, 0, sizeof(h->launches));
+  }
+  return PIC_OK;
+}
+
+int pic_profile_read(pic_handle* h, double* ms_sum, int64_t* launches) {
+  if (!h) return PIC_EINVAL;
+  HIPCHK(h, hipSetDevice(h->cfg.device_id));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  prof_drain(h);
+  for (int i = 0; i < 8; ++i) {
+    if (ms_sum) ms_sum[i] = h->ms_sum[i];
+    if (launches) launches[i] = h->launches[i];
+  }
+  return PIC_OK;
+}
+
+int pic_bad_count(pic_handle* h, int64_t* count) {
+  if (!h || !count) return PIC_EINVAL;
+  HIPCHK(h, hipSetDevice(h->cfg.device_id));
+  unsigned long long c = 0;
+  HIPCHK(h, hipMemcpyAsync(&c, h->bad, sizeof(c), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  *count = (int64_t)c;
+  return PIC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,3 @@
+from .pic import PIC
+from .batched import BatchedPIC
+from .dist import TwoStream, BumpOnTail

@@ -1,0 +1,111 @@
+"""Batched rollout environments: `num_envs` independent PIC systems stepped by one
+libpicstep handle on one MI355X (BASELINE configs 2-5).  Nothing couples the
+environments inside a step; across GPUs they are sharded rank-wise
+(`..parallel.ShardedPIC`), never split.
+"""
+from typing import Optional
+
+import numpy as np
+
+from .. import _abi
+
+
+class _DeviceView:
+    """Minimal __cuda_array_interface__ carrier so torch can alias library-owned memory."""
+
+    def __init__(self, ptr, shape, typestr, strides=None):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False),
+                                         "version": 2, "strides": strides}
+
+
+class BatchedPIC:
+    def __init__(self, num_envs: int, N: int, N_mesh: int, n0: float = 1.0, L: float = 50.0, dt: float = 0.1,
+                 gamma: float = 5.0, interpol: str = "CIC", device: int = 0, dtype="float64", accum_dtype=None,
+                 blocks_per_env: int = 0, verbose: bool = False):
+        self.num_envs, self.N, self.N_mesh = int(num_envs), int(N), int(N_mesh)
+        self.n0, self.L, self.gamma, self.interpol = n0, L, gamma, interpol
+        self.dx = L / N_mesh
+        # CFL clamp of PIC.initialize (src/env/pic.py:71-73)
+        self.dt = dt
+        if self.dt > 2 / np.sqrt(self.N / self.L):
+            self.dt = 2 / np.sqrt(self.N / self.L)
+            if verbose:
+                print("CFL condtion invalid: change dt = {:.4f}".format(self.dt))
+        self.device = device
+        self.dtype = np.dtype(dtype)
+        self._h = _abi.Handle(self.N, self.N_mesh, self.num_envs, L, n0, self.dt, gamma, self.dtype, accum_dtype,
+                              interpol, device, blocks_per_env)
+
+    # reset(x0, v0): x0, v0 are [num_envs, N] with any velocity perturbation already applied
+    def reset(self, x0, v0):
+        self._h.reset(x0, v0)
+
+    def reset_device(self, x_ptr, v_ptr):
+        self._h.reset_device(x_ptr, v_ptr)
+
+    def step(self, E_external: Optional[np.ndarray] = None, nsteps: int = 1):
+        """nsteps x update_state for every environment; asynchronous (call sync() or a getter)."""
+        self._h.step(E_external, nsteps)
+
+    def step_device(self, E_ext_ptr=0, nsteps: int = 1):
+        self._h.step_device(E_ext_ptr, nsteps)
+
+    def sync(self):
+        self._h.sync()
+
+    def get_state(self):
+        """[num_envs, 2N] float64: per environment the reference's get_state() column, flattened."""
+        x, v = self._h.particles()
+        return np.concatenate([x, v], axis=1).astype(np.float64)
+
+    def particles(self):
+        return self._h.particles()
+
+    def fields(self):
+        return self._h.fields()
+
+    def energies(self):
+        """(KE, PE, PE_reward), each [num_envs]."""
+        return self._h.energies()
+
+    def rewards(self):
+        """max(1 - PE_reward, 0) per environment (reward.py:72 with r_pe_n = 1)."""
+        return np.maximum(1.0 - self._h.energies()[2], 0.0)
+
+    def gather_E(self):
+        return self._h.gather_E()
+
+    def eval_field(self, x, E_ext=None):
+        return self._h.eval_field(x, E_ext)
+
+    def bad_count(self):
+        return self._h.bad_count()
+
+    def profile(self, enable=True):
+        self._h.profile(enable)
+
+    def profile_read(self):
+        return self._h.profile_read()
+
+    def torch_views(self):
+        """Zero-copy torch tensors over the device state: x, v [num_envs, N] (strided), n, E_mesh,
+        phi [num_envs, Ng], KE, PE, PE_reward [num_envs].  Call sync() before reading them on
+        another stream."""
+        import torch
+
+        p = self._h.device_ptrs()
+        ts = "<f8" if self.dtype == np.float64 else "<f4"
+        isz = self.dtype.itemsize
+        dev = f"cuda:{self.device}"
+        out = {}
+        for k in ("x", "v"):
+            view = _DeviceView(p[k], (self.num_envs, self.N), ts, (p["ld"] * isz, isz))
+            out[k] = torch.as_tensor(view, device=dev)
+        for k in ("n", "E_mesh", "phi"):
+            out[k] = torch.as_tensor(_DeviceView(p[k], (self.num_envs, self.N_mesh), "<f8"), device=dev)
+        for k in ("KE", "PE", "PE_reward"):
+            out[k] = torch.as_tensor(_DeviceView(p[k], (self.num_envs,), "<f8"), device=dev)
+        return out
+
+    def close(self):
+        self._h.close()

@@ -1,0 +1,246 @@
+"""`PIC` -- drop-in for the reference environment ``src/env/pic.py:11-223`` whose step runs on
+the MI355X through libpicstep.so.
+
+Same constructor keywords, methods and attribute names/shapes as the reference
+class, so ``run_wo_oc.py`` style loops and ``src/control/rl/{ddpg,ppo,sac}.train``
+drive it unchanged: ``update_state(E_external)`` (= step), ``reinit()`` (= reset),
+``get_state()``, ``get_energy()``, ``get_electric_energy()``, ``simulate()``,
+``update_params()``, ``x, v, n, E, E_mesh, phi_mesh, indx_l/r, weight_l/r, dt, dx,
+N, N_mesh, L, n0, init_dist``.  Added: ``step()/reset()`` Gym-style aliases.
+
+State lives on the device; the array attributes are host copies fetched lazily
+and cached until the next step.  ``phi_mesh`` is returned in the zero-mean gauge
+(the reference's gauge is a round-off artefact of its singular Sherman-Morrison
+solve; ``E_mesh`` is gauge free -- DESIGN.md).
+"""
+from typing import Callable, List, Optional
+
+import numpy as np
+
+from .. import _abi
+
+
+class PIC:
+    np.random.seed(42)   # the reference seeds the global RNG when its class body runs (pic.py:12)
+
+    def __init__(self, N: int = 40000, N_mesh: int = 400, n0: float = 1.0, L: float = 50.0, dt: float = 1.0,
+                 tmin: float = 0.0, tmax: float = 50.0, gamma: float = 5.0, A: float = 0.1, n_mode: int = 4,
+                 interpol: str = "CIC", init_dist=None, device: int = 0, dtype="float64"):
+        self.N = N
+        self.N_mesh = N_mesh
+        self.n0 = n0
+        self.L = L
+        self.dt = dt
+        self.tmin = tmin
+        self.tmax = tmax
+        self.dx = L / N_mesh
+        self.gamma = gamma
+        self.A = A
+        self.n_mode = n_mode
+        self.init_dist = init_dist
+        self.interpol = interpol
+        self.device = device
+        self.dtype = np.dtype(dtype)
+        self._handle = None
+        self._handle_key = None
+        self._cache = {}
+        self._fields_hidden = False
+        self.initialize()
+
+    # -- device plumbing ---------------------------------------------------------------------
+    def _key(self):
+        return (self.N, self.N_mesh, float(self.L), float(self.n0), float(self.dt), self.interpol, self.device,
+                str(self.dtype))
+
+    def _ensure_handle(self):
+        key = self._key()
+        if self._handle is None or key != self._handle_key:
+            carry = None
+            if self._handle is not None:
+                if key[0] == self._handle_key[0]:
+                    carry = self._handle.particles()
+                self._handle.close()
+            self._handle = _abi.Handle(self.N, self.N_mesh, 1, self.L, self.n0, self.dt, self.gamma, self.dtype,
+                                       None, self.interpol, self.device)
+            self._handle_key = key
+            if carry is not None:
+                self._handle.reset(*carry)
+        return self._handle
+
+    def _invalidate(self):
+        self._cache = {}
+
+    def _particles(self):
+        if "x" not in self._cache:
+            x, v = self._ensure_handle().particles()
+            self._cache["x"] = x.astype(np.float64).reshape(-1, 1)
+            self._cache["v"] = v.astype(np.float64).reshape(-1, 1)
+        return self._cache["x"], self._cache["v"]
+
+    def _fields(self):
+        if "n" not in self._cache:
+            n, E, phi = self._ensure_handle().fields()
+            self._cache["n"] = n[0].copy()
+            self._cache["E_mesh"] = E[0].reshape(-1, 1).copy()
+            self._cache["phi_mesh"] = phi[0].reshape(-1, 1).copy()
+        return self._cache
+
+    # -- attributes of the reference object --------------------------------------------------
+    @property
+    def x(self):
+        return self._particles()[0]
+
+    @x.setter
+    def x(self, value):
+        _, v = self._particles()
+        self._load(np.asarray(value, dtype=float).reshape(-1), v.reshape(-1))
+
+    @property
+    def v(self):
+        return self._particles()[1]
+
+    @v.setter
+    def v(self, value):
+        x, _ = self._particles()
+        self._load(x.reshape(-1), np.asarray(value, dtype=float).reshape(-1))
+
+    def _load(self, x, v):
+        self._ensure_handle().reset(x, v)
+        self._invalidate()
+
+    @property
+    def n(self):
+        return self._fields()["n"]
+
+    @property
+    def E_mesh(self):
+        return None if self._fields_hidden else self._fields()["E_mesh"]
+
+    @property
+    def phi_mesh(self):
+        return None if self._fields_hidden else self._fields()["phi_mesh"]
+
+    @property
+    def E(self):
+        if self._fields_hidden:
+            return None
+        if "E" not in self._cache:
+            self._cache["E"] = self._ensure_handle().gather_E()[0].astype(np.float64).reshape(-1, 1)
+        return self._cache["E"]
+
+    def _cic(self):
+        if "cic" not in self._cache:
+            if self.interpol != "CIC":
+                raise NotImplementedError("indx_*/weight_* are exposed for CIC only")
+            jl, jr, wl, wr = self._ensure_handle().cic(0)
+            self._cache["cic"] = (jl.reshape(-1, 1), jr.reshape(-1, 1), wl.reshape(-1, 1), wr.reshape(-1, 1))
+        return self._cache["cic"]
+
+    indx_l = property(lambda self: self._cic()[0])
+    indx_r = property(lambda self: self._cic()[1])
+    weight_l = property(lambda self: self._cic()[2])
+    weight_r = property(lambda self: self._cic()[3])
+    indx_m = property(lambda self: None)
+    weight_m = property(lambda self: None)
+
+    # -- reference methods -------------------------------------------------------------------
+    def initialize(self):
+        """pic.py:63-77: fresh sample, velocity perturbation, CFL clamp, density + field."""
+        self.init_dist.reinit()
+        x, v = self.init_dist.get_sample()
+        x = x.reshape(-1, 1)
+        v = v.reshape(-1, 1)
+        v *= (1 + self.A * np.sin(2 * np.pi * self.n_mode * x / self.L))
+        if self.dt > 2 / np.sqrt(self.N / self.L):
+            self.dt = 2 / np.sqrt(self.N / self.L)
+            print("CFL condtion invalid: change dt = {:.4f}".format(self.dt))
+        self._ensure_handle().reset(x, v)     # update_density + update_E_field on the device
+        self._invalidate()
+        self._fields_hidden = False
+
+    def update_params(self, **kwargs):
+        for key in kwargs.keys():
+            if hasattr(self, key) is True and kwargs[key] is not None:
+                setattr(self, key, kwargs[key])
+        self.dx = self.L / self.N_mesh if ("L" in kwargs or "N_mesh" in kwargs) else self.dx
+
+    def reinit(self):
+        """pic.py:84-91: re-initialise; E, E_mesh, phi_mesh read None until the next step."""
+        self.initialize()
+        self._fields_hidden = True
+
+    def update_density(self):
+        self._ensure_handle().refresh()
+        self._invalidate()
+
+    def update_E_field(self):
+        self._ensure_handle().refresh()
+        self._invalidate()
+        self._fields_hidden = False
+
+    def update_state(self, E_external: Optional[np.ndarray] = None):
+        """pic.py:131-146: one Yoshida-4 step with an optional external mesh field (Ng,1)."""
+        h = self._ensure_handle()
+        if E_external is not None:
+            E_external = np.asarray(E_external, dtype=np.float64).reshape(-1)
+            if E_external.shape[0] != self.N_mesh:
+                raise ValueError("E_external must have N_mesh entries")
+        h.step(E_external, 1)
+        self._invalidate()
+        self._fields_hidden = False
+
+    def update_state_w_input_func(self, input_func: Optional[Callable]):
+        # pic.py:148-163 re-evaluates input_func at every sub-stage state; nothing in the reference calls it
+        # (run_feedback.py:146 is commented out) and it would force a host round trip per sub-stage.
+        raise NotImplementedError("update_state_w_input_func is not part of the accelerated path")
+
+    def get_state(self):
+        x, v = self._particles()
+        return np.concatenate([x.copy().reshape(-1, 1), v.copy().reshape(-1, 1)], axis=0)
+
+    def get_energy(self):
+        ke, pe, _ = self._ensure_handle().energies()
+        return float(ke[0] + pe[0])
+
+    def get_electric_energy(self):
+        return float(self._ensure_handle().energies()[1][0])
+
+    def get_kinetic_energy(self):
+        return float(self._ensure_handle().energies()[0][0])
+
+    def get_reward_electric_energy(self):
+        """0.5*sum(E_mesh^2)*dx of the current state = Reward.compute_electric_energy(get_state())."""
+        return float(self._ensure_handle().energies()[2][0])
+
+    def simulate(self, E_external_traj: Optional[List[np.ndarray]] = None):
+        """pic.py:175-223: returns snapshot (2N, Nt+1), E (Nt+1,), PE (Nt+1,)."""
+        Nt = int(np.ceil((self.tmax - self.tmin) / self.dt))
+        pos, vel, Es, PEs = [self.x.copy()], [self.v.copy()], [self.get_energy()], [self.get_electric_energy()]
+        for i in range(Nt):
+            self.update_state(None if E_external_traj is None else E_external_traj[i])
+            pos.append(self.x.copy())
+            vel.append(self.v.copy())
+            Es.append(self.get_energy())
+            PEs.append(self.get_electric_energy())
+        snapshot = np.concatenate([np.concatenate(pos, axis=1), np.concatenate(vel, axis=1)], axis=0)
+        return snapshot, np.array(Es), np.array(PEs)
+
+    # -- Gym-style aliases (north star) ------------------------------------------------------
+    def reset(self):
+        self.reinit()
+        return self.get_state()
+
+    def step(self, E_external: Optional[np.ndarray] = None):
+        """-> (obs, reward, done, info); reward = max(1 - PE_r, 0) of the PRE-step state, i.e. the
+        electric-energy term of Reward.compute_reward (src/control/rl/reward.py:72) as the trainers
+        evaluate it (ddpg.py:455)."""
+        pe_pre = self.get_reward_electric_energy()
+        self.update_state(E_external)
+        ke, pe, per = self._ensure_handle().energies()
+        info = {"KE": float(ke[0]), "PE": float(pe[0]), "PE_reward": float(per[0])}
+        return self.get_state(), max(1.0 - pe_pre, 0.0), False, info
+
+    def close(self):
+        if self._handle is not None:
+            self._handle.close()
+            self._handle = None

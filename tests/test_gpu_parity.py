@@ -1,0 +1,365 @@
+"""Parity of the HIP path (through the C ABI) with the reference: golden vectors produced by the
+reference itself (tests/golden) and the NumPy oracle on seeded inputs.
+
+Tolerances (north star: <= 1e-6 relative, fp64): single evaluations are checked at 1e-12, K-step
+trajectories at bounds that follow the measured growth of rounding differences in this chaotic
+system (a mere particle permutation of the reference moves E_mesh by 1e-12 after 500 steps).
+Positions are compared on the circle (x = 0 and x = L - eps are neighbours).
+"""
+import numpy as np
+import pytest
+
+from conftest import circ_err, load_golden, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def oc():
+    import ocplasma_amd
+    return ocplasma_amd
+
+
+@pytest.fixture(scope="module")
+def po():
+    from oracle import pic_oracle
+    return pic_oracle
+
+
+class FixedDist:
+    """init_dist stand-in that hands PIC the particles a golden file recorded (pic.py:64-65)."""
+
+    def __init__(self, x, v):
+        self.x_init, self.v_init = np.array(x, dtype=float).ravel(), np.array(v, dtype=float).ravel()
+        self.n_samples = self.x_init.size
+
+    def reinit(self):
+        pass
+
+    def get_sample(self):
+        return self.x_init.copy(), self.v_init.copy()
+
+    def get_init_state(self):
+        return np.concatenate([self.x_init.reshape(-1, 1), self.v_init.reshape(-1, 1)], axis=0)
+
+
+def make_pic(oc, g, interpol="CIC", dtype="float64"):
+    return oc.PIC(N=int(g["N"]), N_mesh=int(g["Ng"]), n0=float(g["n0"]), L=float(g["L"]), dt=float(g["dt_in"]),
+                  gamma=float(g["gamma"]), A=float(g["A"]), n_mode=int(g["n_mode"]), interpol=interpol,
+                  init_dist=FixedDist(g["x0_raw"], g["v0_raw"]), dtype=dtype)
+
+
+# ---------------------------------------------------------------------------------------------
+# single evaluations against the reference's own outputs
+# ---------------------------------------------------------------------------------------------
+def test_g1_deposit_edge_inputs(oc):
+    g = load_golden("g1_deposit")
+    L, Ng, n0 = float(g["L"]), int(g["Ng"]), float(g["n0"])
+    x = g["x"][:, 0]
+    h = oc._abi.Handle(x.size, Ng, 1, L, n0, 0.1)
+    n, E, pe = h.eval_field(x[None])
+    assert rel_err(n[0], g["n"]) < 1e-13
+    # reset() stores the doubly wrapped positions (pic.py:139 + util.py:51) and reports CIC bookkeeping
+    h.reset(x[None], np.zeros_like(x)[None])
+    xw, _ = h.particles()
+    assert np.array_equal(xw[0], g["x_wrapped"][:, 0] % L)      # reference leaves exactly-L values for CIC's own mod
+    jl, jr, wl, wr = h.cic(0)
+    assert np.array_equal(jl, g["jl"][:, 0]) and np.array_equal(jr, g["jr"][:, 0])
+    assert np.array_equal(wl, g["wl"][:, 0]) and np.array_equal(wr, g["wr"][:, 0])
+    assert h.bad_count() == 0
+    ht = oc._abi.Handle(x.size, Ng, 1, L, n0, 0.1, interpol="TSC")
+    nt, _, _ = ht.eval_field(x[None])
+    assert rel_err(nt[0], g["tsc_n"]) < 1e-13
+
+
+def test_g3_compute_E(oc):
+    g = load_golden("g3_compute_E")
+    L, Ng, n0 = float(g["L"]), int(g["Ng"]), float(g["n0"])
+    x = g["x"][:, 0]
+    N = x.size
+    h = oc._abi.Handle(N, Ng, 1, L, n0, 0.1)
+    n, E, pe = h.eval_field(x[None])
+    assert rel_err(E[0], g["E_mesh"]) < 1e-12
+    assert abs(pe[0] * N / L / float(g["PE"]) - 1) < 1e-12
+    n, E, pe = h.eval_field(x[None], g["E_ext"])
+    assert rel_err(E[0], g["E_mesh_with_ext"]) < 1e-12
+    # gather at the particles + zero-mean phi
+    h.reset(x[None], (0.5 * x)[None])
+    assert rel_err(h.gather_E()[0], g["E"]) < 1e-12
+    _, Em, phi = h.fields()
+    ref_phi = g["phi_mesh"][:, 0]
+    assert rel_err(phi[0], ref_phi - ref_phi.mean()) < 1e-10
+    ke, pe2, _ = h.energies()
+    assert abs((ke[0] + pe2[0]) / float(g["H"]) - 1) < 1e-13
+    ht = oc._abi.Handle(N, Ng, 1, L, n0, 0.1, interpol="TSC")
+    _, Et, _ = ht.eval_field(x[None], g["E_ext"])
+    assert rel_err(Et[0], g["tsc_E_mesh_with_ext"]) < 1e-12
+
+
+def test_g2_mesh_sizes_field_solve(oc, po):
+    """Field from a density for Ng in {128, 250, 256, 1024} (reference n -> E in g2_solve)."""
+    g = load_golden("g2_solve")
+    L, n0 = float(g["L"]), float(g["n0"])
+    rng = np.random.default_rng(5)
+    for Ng in (128, 250, 256, 1024):
+        x = rng.uniform(0, L, 20000)
+        h = oc._abi.Handle(x.size, Ng, 1, L, n0, 0.1)
+        n, E, _ = h.eval_field(x[None])
+        u = x.reshape(-1, 1).copy()
+        _, Eo = po.field_at_particles(u, L / Ng, Ng, n0, L, x.size)
+        assert rel_err(E[0], Eo) < 5e-12, Ng
+        # the golden pair (n, E) of the reference satisfies the same discrete relation as ours
+        Eref = g[f"E_{Ng}_g5.0"]
+        b = g[f"n_{Ng}"] - n0
+        G = np.cumsum(b) * (L / Ng)
+        G -= G.mean()
+        assert rel_err(-(G + np.roll(G, 1)) / 2, Eref) < 5e-12
+
+
+# ---------------------------------------------------------------------------------------------
+# trajectories through the PIC drop-in class
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["g5_bump_on_tail_N10000_Ng128", "g5_two_stream_N5000_Ng250"])
+def test_g5_trajectory(oc, name):
+    g = load_golden(name)
+    L = float(g["L"])
+    sim = make_pic(oc, g)
+    assert sim.dt == float(g["dt"])
+    assert np.array_equal(sim.x, g["x_init"]) and np.array_equal(sim.v, g["v_init"])
+    assert rel_err(sim.E_mesh, g["E_mesh_init"]) < 1e-12 and rel_err(sim.E, g["E_init"]) < 1e-12
+    rew = oc.Reward(sim.init_dist.get_init_state(), int(g["Ng"]), L, -25.0, 25.0, 1.0, 1.0, 1.0)
+    H, PE, KE, PEr, R = [sim.get_energy()], [sim.get_electric_energy()], [sim.get_kinetic_energy()], [], []
+    tol = {1: 1e-12, 10: 1e-11, 100: 1e-9, 500: 1e-6}
+    for k in range(1, 501):
+        if k <= 100:
+            st = sim.get_state()
+            R.append(rew.compute_reward(st, g["actions"][k - 1]))
+            PEr.append(sim.get_reward_electric_energy())
+        sim.update_state(None)
+        H.append(sim.get_energy()); PE.append(sim.get_electric_energy()); KE.append(sim.get_kinetic_energy())
+        if k in tol:
+            t = tol[k]
+            assert circ_err(sim.x, g[f"x_{k}"], L) / L < t, k
+            assert rel_err(sim.v, g[f"v_{k}"]) < t, k
+            assert rel_err(sim.E_mesh, g[f"E_mesh_{k}"]) < 100 * t, k
+            assert rel_err(sim.n, g[f"n_{k}"]) < t, k
+    assert rel_err(H, g["H"]) < 1e-10
+    assert rel_err(KE, g["KE"]) < 1e-8
+    assert rel_err(PE[:101], g["PE"][:101]) < 1e-8
+    assert rel_err(PEr, g["PE_reward"][:100]) < 1e-8
+    assert rel_err(R, g["reward"][:100]) < 1e-10
+    sim.close()
+
+
+@pytest.mark.parametrize("name,interpol", [("g4_bump_on_tail_ext_N4000_Ng256", "CIC"),
+                                           ("g4_two_stream_ext_N3000_Ng200", "CIC"),
+                                           ("g4_tsc_bump_on_tail_ext_N3000_Ng128", "TSC")])
+def test_g4_external_field_steps(oc, name, interpol):
+    g = load_golden(name)
+    L, Ng = float(g["L"]), int(g["Ng"])
+    mm = g["actions"].shape[1] // 2
+    sim = make_pic(oc, g, interpol)
+    act = oc.E_field(L, Ng, mm)
+    rew = oc.Reward(sim.init_dist.get_init_state(), Ng, L, -25.0, 25.0, 1.0, 1.0, 1.0)
+    R, H = [], [sim.get_energy()]
+    for k in range(1, 21):
+        a = g["actions"][k - 1]
+        act.update_E(a[:mm], a[mm:])
+        R.append(rew.reward_from_energy(sim.get_reward_electric_energy(), a))
+        sim.update_state(E_external=act.compute_E())
+        H.append(sim.get_energy())
+        if k == 1:
+            assert circ_err(sim.x, g["x_1"], L) / L < 1e-13 and rel_err(sim.v, g["v_1"]) < 1e-13
+            assert rel_err(sim.n, g["n_1"]) < 1e-12 and rel_err(sim.E_mesh, g["E_mesh_1"]) < 1e-11
+            assert rel_err(sim.E, g["E_1"]) < 1e-11
+            p, pr = sim.phi_mesh, g["phi_mesh_1"]
+            assert rel_err(p, pr - pr.mean()) < 1e-9
+            if interpol == "CIC":
+                assert np.array_equal(sim.indx_l, g["indx_l_1"]) and np.array_equal(sim.indx_r, g["indx_r_1"])
+                assert rel_err(sim.weight_l, g["weight_l_1"]) < 1e-9 and rel_err(sim.weight_r, g["weight_r_1"]) < 1e-9
+    assert circ_err(sim.x, g["x_20"], L) / L < 1e-10 and rel_err(sim.v, g["v_20"]) < 1e-10
+    assert rel_err(sim.E_mesh, g["E_mesh_20"]) < 1e-9
+    assert rel_err(H, g["H"]) < 1e-12
+    if interpol == "CIC":
+        assert rel_err(R, g["reward"]) < 1e-10
+    sim.close()
+
+
+def test_reward_and_spectrum_on_host_states(oc):
+    """Reward.compute_reward / compute_E_k_spectrum fed with host states, as the trainers call them."""
+    g = load_golden("g5_two_stream_N5000_Ng250")
+    st = np.concatenate([g["x_10"], g["v_10"]], 0)
+    rew = oc.Reward(np.concatenate([g["x0_raw"], g["v0_raw"]]).reshape(-1, 1), 250, 50.0, -25.0, 25.0, 1.0, 1.0, 1.0)
+    assert abs(rew.compute_electric_energy(st) / g["PE_reward"][10] - 1) < 1e-9
+    assert abs(rew.compute_reward(st, g["actions"][10]) - g["reward"][10]) < 1e-10
+    s = load_golden("g9_spectrum")
+    snap = np.concatenate([st, np.concatenate([g["x_100"], g["v_100"]], 0)], 1)
+    ks, Ek = oc.compute_E_k_spectrum(1.0, 50.0, 50.0 / 250, 250, snap, False)
+    assert np.allclose(ks[:8], s["ks"], rtol=1e-14) and rel_err(Ek[:8], s["Ek"]) < 1e-10
+
+
+def test_reference_style_loop_and_gym_aliases(oc):
+    """run_wo_oc.py:108-125 shaped loop + reinit semantics (fields read None until the next step)."""
+    np.random.seed(3)
+    dist = oc.BumpOnTail(a=0.2, v0=3.0, sigma=1.0, n_samples=6000, L=50.0)
+    sim = oc.PIC(N=6000, N_mesh=128, n0=1.0, L=50.0, dt=0.1, tmin=0.0, tmax=1.0, gamma=5.0, A=0.1, n_mode=2,
+                 interpol="CIC", init_dist=dist)
+    E0 = sim.get_energy()
+    pos = []
+    for _ in range(10):
+        sim.update_state(None)
+        pos.append(sim.x.copy())
+        assert sim.get_state().shape == (12000, 1)
+    assert abs(sim.get_energy() / E0 - 1) < 1e-3
+    assert pos[0].shape == (6000, 1) and (pos[-1] >= 0).all() and (pos[-1] < 50.0).all()
+    sim.reinit()
+    assert sim.E is None and sim.E_mesh is None and sim.phi_mesh is None
+    obs, r, done, info = sim.step(None)
+    assert obs.shape == (12000, 1) and 0.0 <= r <= 1.0 and not done and info["KE"] > 0
+    assert sim.E_mesh.shape == (128, 1)
+    snap, E, PE = sim.simulate(None)
+    assert snap.shape == (12000, 11) and E.shape == (11,) and PE.shape == (11,)
+    assert sim.reset().shape == (12000, 1)
+    sim.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# against the oracle on seeded synthetic ensembles
+# ---------------------------------------------------------------------------------------------
+def test_batched_envs_match_oracle_and_single_env(oc, po):
+    E_, N, Ng, L = 5, 30011, 256, 50.0          # odd N: exercises the scalar tail and the padded stride
+    xs, vs = zip(*[po.synthetic_bump_on_tail(N, L, seed=100 + e) for e in range(E_)])
+    x0, v0 = np.stack(xs), np.stack(vs)
+    act = oc.E_field(L, Ng, 3)
+    rng = np.random.default_rng(1)
+    env = oc.BatchedPIC(E_, N, Ng, L=L, dt=0.1)
+    env.reset(x0, v0)
+    refs = [po.OraclePIC(x0[e], v0[e], Ng, L=L, dt=0.1, perturb=False, faithful=False) for e in range(E_)]
+    for k in range(5):
+        ext = act.compute_E_batched(rng.uniform(-1.25, 1.25, (E_, 6)))
+        env.step(ext)
+        for e in range(E_):
+            refs[e].update_state(ext[e].reshape(-1, 1))
+    x, v = env.particles()
+    n, Em, phi = env.fields()
+    ke, pe, per = env.energies()
+    Ep = env.gather_E()
+    for e in range(E_):
+        assert circ_err(x[e], refs[e].x, L) / L < 1e-12 and rel_err(v[e], refs[e].v) < 1e-12
+        assert rel_err(n[e], refs[e].n) < 1e-12 and rel_err(Em[e], refs[e].E_mesh) < 1e-10
+        assert rel_err(Ep[e], refs[e].E) < 1e-10
+        assert abs(ke[e] / refs[e].kinetic_energy() - 1) < 1e-13
+        assert abs(pe[e] / refs[e].get_electric_energy() - 1) < 1e-9
+    assert env.bad_count() == 0
+    # environment 3 stepped alone gives the same answer as inside the batch (up to deposit order)
+    solo = oc.BatchedPIC(1, N, Ng, L=L, dt=0.1)
+    solo.reset(x0[3:4], v0[3:4])
+    rng = np.random.default_rng(1)
+    for k in range(5):
+        solo.step(act.compute_E_batched(rng.uniform(-1.25, 1.25, (E_, 6)))[3:4])
+    xs_, vs_ = solo.particles()
+    assert circ_err(xs_[0], x[3], L) / L < 1e-13 and rel_err(vs_[0], v[3]) < 1e-13
+
+
+def test_nsteps_in_one_call_equals_repeated_calls(oc, po):
+    N, Ng, L = 20000, 128, 50.0
+    x0, v0 = po.synthetic_two_stream(N, L, seed=9)
+    a = oc.BatchedPIC(2, N, Ng, L=L, dt=0.05)
+    b = oc.BatchedPIC(2, N, Ng, L=L, dt=0.05)
+    for env in (a, b):
+        env.reset(np.stack([x0, x0[::-1]]), np.stack([v0, v0[::-1]]))
+    a.step(None, nsteps=7)
+    for _ in range(7):
+        b.step(None)
+    (xa, va), (xb, vb) = a.particles(), b.particles()
+    assert circ_err(xa, xb, L) / L < 1e-13 and rel_err(va, vb) < 1e-13
+    # permutation invariance: env 1 holds env 0's particles in reverse order
+    assert circ_err(xa[0], xa[1][::-1], L) / L < 1e-12 and rel_err(a.fields()[1][0], a.fields()[1][1]) < 1e-11
+
+
+def test_full_size_invariants_and_one_step_parity(oc, po):
+    """BASELINE config-2 sized environments (N = 1e6, Ng = 256): one-step parity with the oracle on
+    environment 0, then size-independent properties over 20 steps."""
+    E_, N, Ng, L, n0 = 4, 1_000_000, 256, 50.0, 1.0
+    dx = L / Ng
+    xs, vs = zip(*[po.synthetic_bump_on_tail(N, L, seed=1234 + e) for e in range(E_)])
+    x0, v0 = np.stack(xs), np.stack(vs)
+    env = oc.BatchedPIC(E_, N, Ng, L=L, dt=0.1)
+    assert abs(env.dt - 2 / np.sqrt(N / L)) < 1e-18            # CFL clamp (pic.py:71-73)
+    env.reset(x0, v0)
+    ref = po.OraclePIC(x0[0], v0[0], Ng, L=L, dt=0.1, perturb=False, faithful=False)
+    ke0, pe0, _ = env.energies()
+    assert abs((ke0[0] + pe0[0]) / ref.get_energy() - 1) < 1e-13
+    env.step()
+    ref.update_state(None)
+    x, v = env.particles()
+    n, Em, phi = env.fields()
+    assert circ_err(x[0], ref.x, L) / L < 1e-13 and rel_err(v[0], ref.v) < 1e-13
+    assert rel_err(n[0], ref.n) < 1e-12 and rel_err(Em[0], ref.E_mesh) < 1e-9
+    env.step(None, nsteps=19)
+    x, v = env.particles()
+    n, Em, phi = env.fields()
+    ke, pe, per = env.energies()
+    assert (x >= 0).all() and (x < L).all() and env.bad_count() == 0
+    assert np.max(np.abs(n.sum(axis=1) * dx - n0 * L)) < 1e-9                 # charge conservation
+    assert np.max(np.abs(Em.mean(axis=1))) < 1e-12 and np.max(np.abs(phi.mean(axis=1))) < 1e-12
+    lap_phi = (np.roll(phi, -1, 1) - 2 * phi + np.roll(phi, 1, 1)) / dx ** 2
+    assert np.max(np.abs(lap_phi - (n - n0))) < 1e-9                          # Poisson residual
+    grad_phi = (np.roll(phi, -1, 1) - np.roll(phi, 1, 1)) / (2 * dx)
+    assert np.max(np.abs(Em + grad_phi)) < 1e-11
+    assert np.allclose(per * N / L, pe, rtol=1e-14)
+    assert np.allclose(0.5 * (v * v).sum(axis=1), ke, rtol=1e-12)
+    assert np.max(np.abs((ke + pe) / (ke0 + pe0) - 1)) < 1e-6                 # energy drift over 20 steps
+
+
+def test_float32_modes_track_float64(oc, po):
+    """fp32 particles (config 3: fp32 accumulator; config 5: fp64 mesh accumulation). Bounds are
+    measured, not derived: single-precision positions on a 50-long box carry ~3e-6 absolute error."""
+    N, Ng, L = 200_000, 512, 50.0
+    x0, v0 = po.synthetic_two_stream(N, L, seed=5)
+    ref = oc.BatchedPIC(1, N, Ng, L=L, dt=0.1)
+    ref.reset(x0[None], v0[None])
+    ref.step(None, 10)
+    _, Er, _ = ref.fields()
+    for acc in ("float32", "float64"):
+        env = oc.BatchedPIC(1, N, Ng, L=L, dt=0.1, dtype="float32", accum_dtype=acc)
+        env.reset(x0[None].astype(np.float32), v0[None].astype(np.float32))
+        env.step(None, 10)
+        x, v = env.particles()
+        assert x.dtype == np.float32 and (x >= 0).all() and (x < L).all()
+        _, E, _ = env.fields()
+        ke, pe, _ = env.energies()
+        kr, pr, _ = ref.energies()
+        assert rel_err(E, Er) < 5e-2, acc
+        assert abs(ke[0] / kr[0] - 1) < 1e-5 and abs(pe[0] / pr[0] - 1) < 5e-2
+
+
+def test_torch_zero_copy_views(oc, po):
+    import torch
+    N, Ng, L = 10000, 128, 50.0
+    x0, v0 = po.synthetic_bump_on_tail(N, L, seed=2)
+    env = oc.BatchedPIC(3, N, Ng, L=L, dt=0.1)
+    env.reset(np.stack([x0] * 3), np.stack([v0] * 3))
+    env.step()
+    env.sync()
+    t = env.torch_views()
+    x, v = env.particles()
+    assert t["x"].is_cuda and t["x"].shape == (3, N)
+    assert np.array_equal(t["x"].cpu().numpy(), x) and np.array_equal(t["v"].cpu().numpy(), v)
+    assert np.array_equal(t["E_mesh"].cpu().numpy(), env.fields()[1])
+    assert np.array_equal(t["PE_reward"].cpu().numpy(), env.energies()[2])
+    obs = torch.cat([t["x"], t["v"]], dim=1)                 # the (2N,) observation, built on device
+    assert np.array_equal(obs.cpu().numpy(), env.get_state())
+
+
+def test_errors_cross_the_abi_as_codes(oc):
+    h = oc._abi.Handle(1000, 64, 1, 50.0, 1.0, 0.1)
+    with pytest.raises(oc._abi.PicError, match="pic_reset first"):
+        h.step()
+    h.reset(np.linspace(0, 49, 1000)[None], np.zeros((1, 1000)))
+    # a NaN position is counted, not followed into memory
+    x = np.linspace(0, 49, 1000)
+    x[5] = np.nan
+    h.reset(x[None], np.zeros((1, 1000)))
+    assert h.bad_count() >= 1
+    h.close()

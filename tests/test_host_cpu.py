@@ -1,0 +1,124 @@
+"""CPU-only checks of the host layer: samplers vs the reference's RNG stream, actuator, the C-ABI
+library's exports, and that the product path refuses to run without a GPU (no fallback)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, load_golden, rel_err
+
+import ocplasma_amd
+from ocplasma_amd import _abi, _build
+from ocplasma_amd.control.actuator import E_field
+from ocplasma_amd.control.reward import Reward, estimate_f, estimate_KL_divergence
+from ocplasma_amd.env.dist import BumpOnTail, TwoStream
+
+
+@pytest.fixture(scope="module")
+def lib_path():
+    return _build.build_library()
+
+
+def test_samplers_reproduce_reference_stream():
+    g = load_golden("g10_samplers")
+    n, L = int(g["n"]), float(g["L"])
+    np.random.seed(int(g["seed"]))
+    ts = TwoStream(v0=3.0, sigma=1.0, n_samples=n, L=L)
+    x1, v1 = ts.get_sample()
+    ts.reinit()
+    x2, v2 = ts.get_sample()
+    assert np.array_equal(x1, g["ts_x1"]) and np.array_equal(v1, g["ts_v1"])
+    assert np.array_equal(x2, g["ts_x2"]) and np.array_equal(v2, g["ts_v2"])
+    assert np.array_equal(ts.get_init_state(), g["ts_init_state"])
+    np.random.seed(int(g["seed"]))
+    bt = BumpOnTail(a=0.2, v0=3.0, sigma=1.0, n_samples=n, L=L)
+    x1, v1 = bt.get_sample()
+    bt.reinit()
+    x2, v2 = bt.get_sample()
+    assert np.array_equal(x1, g["bt_x1"]) and np.array_equal(v1, g["bt_v1"])
+    assert np.array_equal(x2, g["bt_x2"]) and np.array_equal(v2, g["bt_v2"])
+    assert np.array_equal(bt.high_indx, g["bt_high_indx"])
+    assert np.array_equal(bt.get_init_state(), g["bt_init_state"])
+
+
+def test_sampler_trajectory_inputs_match_golden():
+    """The x0/v0 the reference drew for the g5 trajectory (seed 42, then PIC.__init__'s redraw)."""
+    g = load_golden("g5_bump_on_tail_N10000_Ng128")
+    np.random.seed(42)
+    d = BumpOnTail(a=0.2, v0=3.0, sigma=1.0, n_samples=10000, L=50.0)
+    d.reinit()     # PIC.initialize redraws (pic.py:64)
+    assert np.array_equal(d.x_init, g["x0_raw"]) and np.array_equal(d.v_init, g["v0_raw"])
+
+
+def test_actuator_matches_golden():
+    g = load_golden("g8_actuator")
+    for Ng, mm in ((128, 3), (250, 5), (256, 1)):
+        a = E_field(float(g["L"]), Ng, mm)
+        E = a.compute_E(g[f"cc_{Ng}_{mm}"], g[f"cs_{Ng}_{mm}"])
+        assert E.shape == (Ng, 1) and np.array_equal(E, g[f"E_{Ng}_{mm}"])
+        a.update_E(g[f"cc_{Ng}_{mm}"], g[f"cs_{Ng}_{mm}"])
+        assert np.array_equal(a.compute_E(), E)
+        acts = np.concatenate([g[f"cc_{Ng}_{mm}"], g[f"cs_{Ng}_{mm}"]])[None]
+        assert rel_err(a.compute_E_batched(acts)[0], E) < 1e-14
+        a.reinit()
+        assert not a.coeff_cos.any()
+
+
+def test_reward_host_pieces():
+    rng = np.random.default_rng(0)
+    st = np.concatenate([rng.uniform(0, 50, 500), rng.normal(0, 1, 500)]).reshape(-1, 1)
+    f = estimate_f(st, 32, 50.0, -25.0, 25.0, 1.0)
+    assert f.shape == (32, 32) and abs(f.sum() * (50 / 32) * (50 / 32) - 1.0) < 1e-9
+    assert abs(estimate_KL_divergence(f, f.copy(), 50 / 32, 50 / 32)) < 1e-6
+    r = Reward.__new__(Reward)
+    r.L = 50.0
+    assert r.compute_input_energy(np.ones(10)) == 10 * 50.0 * 0.25
+
+
+def test_header_symbols_are_exported(lib_path):
+    hdr = open(os.path.join(ROOT, "include", "picstep.h")).read()
+    declared = set(re.findall(r"^(?:int|const char\*)\s+(pic_[A-Za-z_]+)\s*\(", hdr, re.M))
+    assert declared == set(_abi.SIGNATURES), declared ^ set(_abi.SIGNATURES)
+    lib = ctypes.CDLL(lib_path)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.pic_abi_version() == _abi.ABI_VERSION
+
+
+def test_config_struct_layout_matches_header():
+    assert ctypes.sizeof(_abi.PicConfig) == 8 + 4 + 4 + 4 * 8 + 6 * 4
+
+
+def test_no_cpu_fallback(lib_path):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(_abi.PicError, match="no HIP device"):
+        _abi.Handle(1000, 64)
+    from ocplasma_amd.env.pic import PIC
+
+    class D:
+        def reinit(self): pass
+        def get_sample(self): return np.zeros(100), np.zeros(100)
+    with pytest.raises(_abi.PicError):
+        PIC(N=100, N_mesh=16, dt=0.1, init_dist=D())
+
+
+def test_bad_config_is_rejected(lib_path):
+    lib = _abi.load()
+    cfg = _abi.PicConfig(0, 64, 1, 50.0, 1.0, 0.1, 5.0, 0, 0, 0, 0, 0, 0)
+    h = ctypes.c_void_p()
+    assert lib.pic_create(ctypes.byref(cfg), ctypes.byref(h)) == -1
+    assert b"N>=1" in lib.pic_last_error(None)
+    cfg = _abi.PicConfig(100, 64, 1, 50.0, 1.0, 0.1, 5.0, 0, 1, 0, 0, 0, 0)   # f32 accumulator, f64 particles
+    assert lib.pic_create(ctypes.byref(cfg), ctypes.byref(h)) == -1
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "optimal-control-1d-electrostatic-plasma_amd")
+    for dp, _, fs in os.walk(pkg):
+        for f in fs:
+            if f.endswith((".py", ".hip", ".h")):
+                assert "oracle" not in open(os.path.join(dp, f)).read(), f
