@@ -41,6 +41,15 @@ def synth_bump_on_tail_device(torch, num_envs, N, L, dtype, device, seed, a=0.2,
     return x.to(dtype).contiguous(), v.to(dtype).contiguous()
 
 
+def pmc_traffic(kernel, args, E, N, Ng):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (FETCH_SIZE x2 +
+    WRITE_SIZE, profiles/summarize.py) -- only when they were taken on this exact workload."""
+    path = os.path.join(ROOT, "profiles", "r1_summary.json")
+    if not os.path.exists(path) or (E, N, Ng, args.dtype) != (64, 1_000_000, 256, "float64"):
+        return None
+    return json.load(open(path)).get("kernels", {}).get(kernel, {}).get("hbm_bytes_per_launch")
+
+
 def cpu_baseline(N, Ng, L, dt, budget_s=20.0):
     """The NumPy oracle with the reference's call structure (7 compute_E + refresh per step, dense
     Ng x Ng operators, np.bincount), one thread, on a bounded sample of the same workload."""
@@ -72,7 +81,7 @@ def main():
     ap.add_argument("--accum", default=None, choices=[None, "float64", "float32"])
     ap.add_argument("--blocks-per-env", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--profile-steps", type=int, default=3)
+    ap.add_argument("--profile-steps", type=int, default=-1, help="steps of the event-bracketed pass (-1 = --steps)")
     args = ap.parse_args()
 
     import torch
@@ -131,12 +140,20 @@ def main():
     drift = float(np.max(np.abs((ke + pe) / (ke0 + pe0) - 1)))
     bad = env.bad_count()
 
-    # per-kernel durations, HIP events on the library's own stream (untimed extra steps)
+    # Per-kernel durations: the same K steps again, every launch bracketed by HIP events on the
+    # library's own stream (the brackets cost ~4 % of a step, so they stay out of `value`).
     roof = None
     kernels = {}
-    if rank == 0 and args.profile_steps > 0:
+    ms_per_step_events = None
+    copy_gbs = env.stream_probe(10) if rank == 0 else None
+    psteps = args.steps if args.profile_steps < 0 else args.profile_steps
+    if rank == 0 and psteps > 0:
         env.profile(True)
-        env.step(None, nsteps=args.profile_steps)
+        env.sync()
+        t1 = time.perf_counter()
+        env.step(None, nsteps=psteps)
+        env.sync()
+        ms_per_step_events = (time.perf_counter() - t1) / psteps * 1e3
         prof = env.profile_read()
         env.profile(False)
         esz = 8 if args.dtype == "float64" else 4
@@ -147,8 +164,10 @@ def main():
         alg_bytes = SWEEP_WORDS[dom] * esz * N * E
         ach = alg_bytes / avg_s / 1e9
         roof = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": ach / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": alg_bytes,
-                "avg_launch_ms": avg_s * 1e3}
+                "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic(dom, args, E, N, Ng),
+                "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_s * 1e3,
+                "ms_per_step_with_event_brackets": ms_per_step_events,
+                "measured_inplace_copy_GBs": copy_gbs}
 
     total_ps = N * E * world * args.steps
     value = total_ps / elapsed

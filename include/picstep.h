@@ -117,6 +117,11 @@ int pic_eval_field(pic_handle* h, const void* x, int mem_kind, const double* E_e
 int pic_profile(pic_handle* h, int enable);
 int pic_profile_read(pic_handle* h, double* ms_sum, int64_t* launches);
 
+/* Streaming ceiling of this device for the sweeps' access shape (read x and v, write x and v, same
+ * grid, no arithmetic): bytes moved per second in GB/s, averaged over `repeats` launches on
+ * scratch arrays of the handle's particle footprint.  bench.py reports it next to the 8 TB/s spec. */
+int pic_stream_probe(pic_handle* h, int repeats, double* gbytes_per_s);
+
 int pic_sync(pic_handle* h);
 /* Number of particle positions found non-finite or out of range by the last sweeps (0 = healthy). */
 int pic_bad_count(pic_handle* h, int64_t* count);

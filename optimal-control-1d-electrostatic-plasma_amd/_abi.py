@@ -51,6 +51,7 @@ SIGNATURES = {
     "pic_eval_field": [_vp, _vp, C.c_int, _vp, _vp, _vp, _vp],
     "pic_profile": [_vp, C.c_int],
     "pic_profile_read": [_vp, _dp, _i64p],
+    "pic_stream_probe": [_vp, C.c_int, _dp],
     "pic_sync": [_vp],
     "pic_bad_count": [_vp, _i64p],
     "pic_last_error": [_vp],
@@ -59,7 +60,22 @@ SIGNATURES = {
 
 
 def library_path():
-    return _build.LIB
+    # PICSTEP_LIB selects a timing-experiment build (see _build.build_variant); default is the product
+    return os.environ.get("PICSTEP_LIB") or _build.LIB
+
+
+def _preload_torch_hip_runtime():
+    """One HIP runtime per process: the torch wheel bundles its own libamdhip64.so (SONAME
+    libamdhip64.so.7, the name libpicstep.so needs).  Loading that copy first makes the dynamic
+    loader bind libpicstep.so to it, so torch tensors and library buffers share one runtime,
+    whichever of the two is imported first.  Without torch the system ROCm runtime is used."""
+    import importlib.util
+    spec = importlib.util.find_spec("torch")
+    if spec is None or not spec.origin:
+        return
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        C.CDLL(cand, mode=C.RTLD_GLOBAL)
 
 
 def load():
@@ -71,6 +87,7 @@ def load():
     if not os.path.exists(path):
         raise PicError(f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                        "(hipcc, gfx950). There is no CPU fallback for the PIC step.")
+    _preload_torch_hip_runtime()
     lib = C.CDLL(path)
     for name, args in SIGNATURES.items():
         fn = getattr(lib, name)
@@ -219,6 +236,11 @@ class Handle:
         cnt = (C.c_int64 * 8)()
         self._chk(self.lib.pic_profile_read(self._h, ms, cnt))
         return {KIND_NAMES[i]: (ms[i], cnt[i]) for i in range(6) if cnt[i]}
+
+    def stream_probe(self, repeats=10):
+        g = C.c_double()
+        self._chk(self.lib.pic_stream_probe(self._h, int(repeats), C.byref(g)))
+        return g.value
 
     def bad_count(self):
         c = C.c_int64()

@@ -26,18 +26,30 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build_library(force=False, verbose=False):
-    """Compile csrc/picstep.hip -> csrc/libpicstep.so. Returns the library path."""
-    if not force and not needs_build():
-        return LIB
+def _compile(out, defines=(), verbose=False):
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         raise RuntimeError("hipcc not found: libpicstep.so can only be built with the ROCm toolchain")
-    cmd = [hipcc] + FLAGS + ["-o", LIB + ".tmp", SRC]
+    cmd = [hipcc] + FLAGS + ["-D" + d for d in defines] + ["-o", out + ".tmp", SRC]
     if verbose:
         print(" ".join(cmd))
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("hipcc failed:\n" + r.stdout + r.stderr)
-    os.replace(LIB + ".tmp", LIB)
-    return LIB
+    os.replace(out + ".tmp", out)
+    return out
+
+
+def build_library(force=False, verbose=False):
+    """Compile csrc/picstep.hip -> csrc/libpicstep.so. Returns the library path."""
+    if not force and not needs_build():
+        return LIB
+    return _compile(LIB, (), verbose)
+
+
+def build_variant(name, defines, verbose=False):
+    """Timing-experiment builds (csrc/exp/libpicstep_<name>.so, selected with PICSTEP_LIB): they
+    change results and are never loaded by default."""
+    d = os.path.join(HERE, "csrc", "exp")
+    os.makedirs(d, exist_ok=True)
+    return _compile(os.path.join(d, f"libpicstep_{name}.so"), defines, verbose)

@@ -29,6 +29,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -57,8 +58,9 @@ struct SweepArgs {
   int Ng;
   int nblk;           // workgroups per env
   int R;              // LDS mesh replicas per workgroup (1, 2 or 4)
-  double L, dx, dt;
-  double c_prev, c_cur, d_cur;
+  int reverse;        // walk environments and chunks from the far end (alternates sweep to sweep)
+  double L, dx, rdx, dt;   // rdx = 1/dx (for float particles: 1/(float)dx)
+  double c_prev, c_cur, d_cur, c_next;
 };
 
 struct SolveArgs {
@@ -98,27 +100,47 @@ __device__ __forceinline__ T wrap_periodic(T q, T L) {
   return r;
 }
 
+// a / dx for the loop-invariant divisor dx, with rdx = 1/dx rounded once on the host: one Newton
+// correction on the reciprocal product, q0 = a rdx; q = q0 + (a - q0 dx) rdx, both steps fused.
+// The value before the final rounding is within ~2^-104 relative of a/dx, so the result is the
+// IEEE quotient unless a/dx lies that close to a rounding boundary (probability ~2^-52 per
+// operation, then 1 ulp off) -- 3 instructions instead of the ~12 of the full v_div_* sequence,
+// which made sweep D division-bound.  tests/ check it bit for bit against true division.
+template <typename T>
+__device__ __forceinline__ T div_dx(T a, T dx, T rdx) {
+#if defined(PIC_EXP_TRUEDIV)
+  return a / dx;
+#elif defined(PIC_EXP_RCPDIV)
+  return a * rdx;
+#else
+  T q0 = a * rdx;
+  T rem = fma(-q0, dx, a);
+  return fma(rem, rdx, q0);
+#endif
+}
+
 // Cell index and shape-function weights at position q.  j is the LDS index of the leftmost
 // touched node (mesh node + OFF, OFF = 1 for TSC so that node -1 has a slot).
 //   CIC (interpolate.py:6-13): jl = floor(xw/dx); wl = ((jl+1) dx - xw)/dx; wr = (xw - jl dx)/dx
 //   TSC (interpolate.py:24-34): d = (xw - jm dx)/dx; wl = .5(1.5-d)^2; wm = .75-(d-1)^2; wr = .5(d-.5)^2
 template <typename T, int SHAPE>
-__device__ __forceinline__ void locate(T q, T L, T dx, int Ng, T& xw, int& j, T (&w)[3], unsigned& bad) {
+__device__ __forceinline__ void locate(T q, T L, T dx, T rdx, int Ng, T& xw, int& j, T (&w)[3], unsigned& bad) {
   xw = wrap_periodic(q, L);
-  T jf = floor(xw / dx);
-  j = (int)jf;
-  if ((unsigned)j >= (unsigned)Ng) {
-    // j == Ng happens when xw/dx rounds up to Ng (undefined in the reference: bincount grows a bin and
-    // solve.py:32 raises); it is folded to node 0.  Anything else is a non-finite position.
-    if (!(j == Ng)) { bad += 1u; jf = T(0); xw = T(0); }
-    j = 0;
+  if (!(xw >= T(0) && xw < L)) {   // NaN / inf position: count it, park it on node 0, never index with it
+    bad += 1u;
+    xw = T(0);
   }
+  T jf = floor(div_dx(xw, dx, rdx));
+  j = (int)jf;
+  // j == Ng happens when xw/dx rounds up to Ng (undefined in the reference: bincount grows a bin and
+  // solve.py:32 raises); it is folded to node 0 with the weights of the unfolded index.
+  if ((unsigned)j >= (unsigned)Ng) j = 0;
   if (SHAPE == PIC_CIC) {
-    w[0] = ((jf + T(1)) * dx - xw) / dx;
-    w[1] = (xw - jf * dx) / dx;
+    w[0] = div_dx((jf + T(1)) * dx - xw, dx, rdx);
+    w[1] = div_dx(xw - jf * dx, dx, rdx);
     w[2] = T(0);
   } else {
-    T d = (xw - jf * dx) / dx;
+    T d = div_dx(xw - jf * dx, dx, rdx);
     T a = T(1.5) - d, b = d - T(1), c = d - T(0.5);
     w[0] = T(0.5) * (a * a);
     w[1] = T(0.75) - b * b;
@@ -135,25 +157,37 @@ __device__ __forceinline__ T gather_field(const T* __restrict__ Es, int j, const
 
 template <typename A, typename T, int SHAPE>
 __device__ __forceinline__ void deposit(A* __restrict__ acc, int j, const T (&w)[3]) {
+#ifdef PIC_EXP_NODEPOSIT   // timing experiment only: keep the operands alive, drop the LDS atomics
+  asm volatile("" ::"v"(w[0]), "v"(w[1]), "v"(j));
+  (void)acc;
+#else
   atomicAdd(&acc[j], (A)w[0]);
   atomicAdd(&acc[j + 1], (A)w[1]);
   if (SHAPE == PIC_TSC) atomicAdd(&acc[j + 2], (A)w[2]);
+#endif
 }
 
+#define PIC_LOAD(p) (*(p))
+#define PIC_STORE(v, p) (*(p) = (v))
+
 template <typename T> struct VecOf;
-template <> struct VecOf<double> { using type = double2; static constexpr int n = 2; };
-template <> struct VecOf<float> { using type = float4; static constexpr int n = 4; };
+typedef double pic_v2d __attribute__((ext_vector_type(2)));   // 16 B per lane either way
+typedef float pic_v4f __attribute__((ext_vector_type(4)));
+template <> struct VecOf<double> { using type = pic_v2d; static constexpr int n = 2; };
+template <> struct VecOf<float> { using type = pic_v4f; static constexpr int n = 4; };
 
 __device__ __forceinline__ double wave_sum(double v) {
   for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
   return v;
 }
 
-// One particle through one sub-stage.  Returns v*v contribution for KE (stages D / REFRESH).
+// One particle through one sub-stage.  Stages D / REFRESH also deposit the NEXT step's first drift
+// position q1 = x' + (c1 p) dt into a second mesh (acc2), which is exactly what sweep A of the next
+// step would deposit from the stored x', p -- so that sweep (a full read of x and v) is skipped.
 template <typename T, typename A, int SHAPE, int STAGE>
 __device__ __forceinline__ void push_one(T& xq, T& vp, const T* __restrict__ Es, A* __restrict__ acc,
-                                         T L, T dx, T dt, T c_prev, T c_cur, T d_cur, int Ng,
-                                         double& ke, unsigned& bad) {
+                                         A* __restrict__ acc2, T L, T dx, T rdx, T dt, T c_prev, T c_cur, T d_cur,
+                                         T c_next, int Ng, double& ke, unsigned& bad) {
   T w[3];
   T xw;
   int j;
@@ -161,104 +195,34 @@ __device__ __forceinline__ void push_one(T& xq, T& vp, const T* __restrict__ Es,
   if (STAGE == ST_A) {
     q = q + (c_cur * p) * dt;                                   // integration.py:42, c1
   } else if (STAGE == ST_B || STAGE == ST_C || STAGE == ST_D) {
-    if (STAGE == ST_B) q = q + (c_prev * p) * dt;               // q1 again (sweep A stores nothing)
-    locate<T, SHAPE>(q, L, dx, Ng, xw, j, w, bad);
+    if (STAGE == ST_B) q = q + (c_prev * p) * dt;               // q1 again (it is never stored)
+    locate<T, SHAPE>(q, L, dx, rdx, Ng, xw, j, w, bad);
     T E = gather_field<T, SHAPE>(Es, j, w);                     // util.py:105 / pic.py:120
     p = p + (d_cur * (-E)) * dt;                                // integration.py:32, pic.py:127
     q = q + (c_cur * p) * dt;                                   // integration.py:42
   }
-  locate<T, SHAPE>(q, L, dx, Ng, xw, j, w, bad);
+  locate<T, SHAPE>(q, L, dx, rdx, Ng, xw, j, w, bad);
   deposit<A, T, SHAPE>(acc, j, w);
   if (STAGE == ST_D || STAGE == ST_REFRESH) {
     q = xw;                                                     // pic.py:139 (+ util.py:51)
     ke += (double)p * (double)p;
+    T qn = q + (c_next * p) * dt;                               // next step's q1 (integration.py:42, c1)
+    T xn;
+    locate<T, SHAPE>(qn, L, dx, rdx, Ng, xn, j, w, bad);
+    deposit<A, T, SHAPE>(acc2, j, w);
   }
   xq = q;
   vp = p;
 }
 
-template <typename T, typename A, int SHAPE, int STAGE>
-__global__ __launch_bounds__(BLOCK) void sweep_kernel(T* __restrict__ x, T* __restrict__ v,
-                                                      const double* __restrict__ Ef,
-                                                      double* __restrict__ part, double* __restrict__ ke_part,
-                                                      unsigned long long* __restrict__ bad_count, SweepArgs a) {
+// fold the periodic ghost slots and the replicas of one LDS mesh, store it as this workgroup's slab row
+template <typename A, int SHAPE>
+__device__ __forceinline__ void flush_mesh(const A* __restrict__ acc_all, int R, int stride, int Ng,
+                                           double* __restrict__ row) {
   constexpr int OFF = (SHAPE == PIC_TSC) ? 1 : 0;
-  constexpr int VEC = VecOf<T>::n;
-  using V = typename VecOf<T>::type;
-  constexpr bool kGather = (STAGE == ST_B || STAGE == ST_C || STAGE == ST_D);
-  constexpr bool kStore = (STAGE == ST_B || STAGE == ST_C || STAGE == ST_D || STAGE == ST_REFRESH);
-  constexpr bool kReadV = (STAGE != ST_PROBE);
-
-  extern __shared__ __align__(16) unsigned char smem_raw[];
-  const int Ng = a.Ng;
-  const int stride = Ng + 2;
-  A* acc_all = reinterpret_cast<A*>(smem_raw);
-  T* Es = reinterpret_cast<T*>(smem_raw + (size_t)a.R * stride * sizeof(A));
-  __shared__ double red[WAVES];
-
-  const int tid = threadIdx.x;
-  const int env = blockIdx.y;
-  const int blk = blockIdx.x;
-
-  for (int i = tid; i < a.R * stride; i += BLOCK) acc_all[i] = A(0);
-  if (kGather) {
-    const double* Ee = Ef + (size_t)env * Ng;
-    for (int i = tid; i < stride; i += BLOCK) {
-      int node = i - OFF;
-      node = node < 0 ? node + Ng : (node >= Ng ? node - Ng : node);
-      Es[i] = (T)Ee[node];
-    }
-  }
-  __syncthreads();
-
-  A* acc = acc_all + (size_t)((tid >> 6) & (a.R - 1)) * stride;
-  const T L = (T)a.L, dx = (T)a.dx, dt = (T)a.dt;
-  const T c_prev = (T)a.c_prev, c_cur = (T)a.c_cur, d_cur = (T)a.d_cur;
-
-  T* xe = x + (size_t)env * a.ld;
-  T* ve = v + (size_t)env * a.ld;
-  const long long begin = (long long)blk * a.chunk;
-  long long end = begin + a.chunk;
-  if (end > a.N) end = a.N;
-
-  double ke = 0.0;
-  unsigned bad = 0u;
-  for (long long i = begin + (long long)tid * VEC; i < end; i += (long long)BLOCK * VEC) {
-    if (i + VEC <= end) {
-      V xv = *reinterpret_cast<const V*>(xe + i);
-      V vv;
-      if (kReadV) vv = *reinterpret_cast<const V*>(ve + i);
-      T* xs = reinterpret_cast<T*>(&xv);
-      T* vs = reinterpret_cast<T*>(&vv);
-#pragma unroll
-      for (int k = 0; k < VEC; ++k) {
-        T pv = kReadV ? vs[k] : T(0);
-        push_one<T, A, SHAPE, STAGE>(xs[k], pv, Es, acc, L, dx, dt, c_prev, c_cur, d_cur, Ng, ke, bad);
-        if (kReadV) vs[k] = pv;
-      }
-      if (kStore) {
-        *reinterpret_cast<V*>(xe + i) = xv;
-        if (STAGE != ST_REFRESH) *reinterpret_cast<V*>(ve + i) = vv;
-      }
-    } else {
-      for (long long k = i; k < end; ++k) {
-        T xq = xe[k];
-        T pv = kReadV ? ve[k] : T(0);
-        push_one<T, A, SHAPE, STAGE>(xq, pv, Es, acc, L, dx, dt, c_prev, c_cur, d_cur, Ng, ke, bad);
-        if (kStore) {
-          xe[k] = xq;
-          if (STAGE != ST_REFRESH) ve[k] = pv;
-        }
-      }
-    }
-  }
-  __syncthreads();
-
-  // fold the periodic ghost slots and the replicas, store this workgroup's row of the slab
-  double* row = part + ((size_t)env * a.nblk + blk) * Ng;
-  for (int c = tid; c < Ng; c += BLOCK) {
+  for (int c = threadIdx.x; c < Ng; c += BLOCK) {
     double s = 0.0;
-    for (int r = 0; r < a.R; ++r) {
+    for (int r = 0; r < R; ++r) {
       const A* ar = acc_all + (size_t)r * stride;
       double t = (double)ar[c + OFF];
       if (SHAPE == PIC_CIC) {
@@ -271,14 +235,105 @@ __global__ __launch_bounds__(BLOCK) void sweep_kernel(T* __restrict__ x, T* __re
     }
     row[c] = s;
   }
+}
 
-  if (STAGE == ST_D || STAGE == ST_REFRESH) {
+template <typename T, typename A, int SHAPE, int STAGE>
+__global__ __launch_bounds__(BLOCK) void sweep_kernel(T* __restrict__ x, T* __restrict__ v,
+                                                      const double* __restrict__ Ef,
+                                                      double* __restrict__ part, double* __restrict__ part2,
+                                                      double* __restrict__ ke_part,
+                                                      unsigned long long* __restrict__ bad_count, SweepArgs a) {
+  constexpr int OFF = (SHAPE == PIC_TSC) ? 1 : 0;
+  constexpr int VEC = VecOf<T>::n;
+  using V = typename VecOf<T>::type;
+  constexpr bool kGather = (STAGE == ST_B || STAGE == ST_C || STAGE == ST_D);
+  constexpr bool kStore = (STAGE == ST_B || STAGE == ST_C || STAGE == ST_D || STAGE == ST_REFRESH);
+  constexpr bool kStoreV = (STAGE == ST_B || STAGE == ST_C || STAGE == ST_D);
+  constexpr bool kReadV = (STAGE != ST_PROBE);
+  constexpr bool kDual = (STAGE == ST_D || STAGE == ST_REFRESH);
+
+  // LDS: [R meshes: acc][R meshes: acc2 (dual stages)][field tile Es]
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  const int Ng = a.Ng;
+  const int stride = Ng + 2;
+  const int nacc = (kDual ? 2 : 1) * a.R * stride;
+  A* acc_all = reinterpret_cast<A*>(smem_raw);
+  A* acc2_all = acc_all + (size_t)a.R * stride;
+  T* Es = reinterpret_cast<T*>(smem_raw + (size_t)2 * a.R * stride * sizeof(A));
+  __shared__ double red[WAVES];
+
+  const int tid = threadIdx.x;
+  // Consecutive sweeps walk memory in opposite directions: what the previous sweep wrote last (still
+  // in the 256 MB Infinity Cache) is what this one reads first.
+  const int env = a.reverse ? (int)gridDim.y - 1 - (int)blockIdx.y : (int)blockIdx.y;
+  const int blk = a.reverse ? (int)gridDim.x - 1 - (int)blockIdx.x : (int)blockIdx.x;
+
+  for (int i = tid; i < nacc; i += BLOCK) acc_all[i] = A(0);
+  if (kGather) {
+    const double* Ee = Ef + (size_t)env * Ng;
+    for (int i = tid; i < stride; i += BLOCK) {
+      int node = i - OFF;
+      node = node < 0 ? node + Ng : (node >= Ng ? node - Ng : node);
+      Es[i] = (T)Ee[node];
+    }
+  }
+  __syncthreads();
+
+  const int rep = (tid >> 6) & (a.R - 1);
+  A* acc = acc_all + (size_t)rep * stride;
+  A* acc2 = acc2_all + (size_t)rep * stride;
+  const T L = (T)a.L, dx = (T)a.dx, rdx = (T)a.rdx, dt = (T)a.dt;
+  const T c_prev = (T)a.c_prev, c_cur = (T)a.c_cur, d_cur = (T)a.d_cur, c_next = (T)a.c_next;
+
+  T* xe = x + (size_t)env * a.ld;
+  T* ve = v + (size_t)env * a.ld;
+  const long long begin = (long long)blk * a.chunk;
+  long long end = begin + a.chunk;
+  if (end > a.N) end = a.N;
+  const long long step = (long long)BLOCK * VEC;
+
+  double ke = 0.0;
+  unsigned bad = 0u;
+  long long i = begin + (long long)tid * VEC;
+  for (; i + VEC <= end; i += step) {
+    V xv = PIC_LOAD(reinterpret_cast<const V*>(xe + i));
+    V vv = {};
+    if (kReadV) vv = PIC_LOAD(reinterpret_cast<const V*>(ve + i));
+    T* xs = reinterpret_cast<T*>(&xv);
+    T* vs = reinterpret_cast<T*>(&vv);
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+      T pv = kReadV ? vs[k] : T(0);
+      push_one<T, A, SHAPE, STAGE>(xs[k], pv, Es, acc, acc2, L, dx, rdx, dt, c_prev, c_cur, d_cur, c_next, Ng, ke, bad);
+      if (kReadV) vs[k] = pv;
+    }
+    if (kStore) {
+      PIC_STORE(xv, reinterpret_cast<V*>(xe + i));
+      if (kStoreV) PIC_STORE(vv, reinterpret_cast<V*>(ve + i));
+    }
+  }
+  for (long long k = i; k < end; ++k) {       // ragged tail (fewer than VEC particles left for this lane)
+    T xq = xe[k];
+    T pv = kReadV ? ve[k] : T(0);
+    push_one<T, A, SHAPE, STAGE>(xq, pv, Es, acc, acc2, L, dx, rdx, dt, c_prev, c_cur, d_cur, c_next, Ng, ke, bad);
+    if (kStore) {
+      xe[k] = xq;
+      if (kStoreV) ve[k] = pv;
+    }
+  }
+  __syncthreads();
+
+  const size_t rowi = ((size_t)env * a.nblk + blk) * Ng;
+  flush_mesh<A, SHAPE>(acc_all, a.R, stride, Ng, part + rowi);
+  if (kDual) flush_mesh<A, SHAPE>(acc2_all, a.R, stride, Ng, part2 + rowi);
+
+  if (kDual) {
     double w = wave_sum(ke);
     if ((tid & 63) == 0) red[tid >> 6] = w;
     __syncthreads();
     if (tid == 0) {
       double s = 0.0;
-      for (int i = 0; i < WAVES; ++i) s += red[i];
+      for (int k = 0; k < WAVES; ++k) s += red[k];
       ke_part[(size_t)env * a.nblk + blk] = s;
     }
   }
@@ -293,6 +348,10 @@ __global__ __launch_bounds__(BLOCK) void sweep_kernel(T* __restrict__ x, T* __re
 // E_j = -(phi_{j+1}-phi_{j-1})/(2dx) = -(G_{j+1/2} + G_{j-1/2})/2.  phi follows from a second
 // scan and is returned with zero mean.
 // ---------------------------------------------------------------------------------------------
+constexpr int SBLOCK = 1024;         // field-solve workgroup: 16 waves
+constexpr int SWAVES = SBLOCK / 64;
+constexpr int SGROUPS = 4;           // slab rows are summed by 4 groups of 256 lanes
+
 __device__ __forceinline__ double wave_incl_scan(double v) {
   const int lane = threadIdx.x & 63;
   for (int off = 1; off < 64; off <<= 1) {
@@ -308,7 +367,7 @@ __device__ __forceinline__ double block_excl_scan(double v, double* ws, double& 
   if (lane == 63) ws[w] = inc;
   __syncthreads();
   double off = 0.0, tot = 0.0;
-  for (int i = 0; i < WAVES; ++i) {
+  for (int i = 0; i < SWAVES; ++i) {
     double s = ws[i];
     if (i < w) off += s;
     tot += s;
@@ -323,12 +382,12 @@ __device__ __forceinline__ double block_sum(double v, double* ws) {
   if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = w;
   __syncthreads();
   double s = 0.0;
-  for (int i = 0; i < WAVES; ++i) s += ws[i];
+  for (int i = 0; i < SWAVES; ++i) s += ws[i];
   __syncthreads();
   return s;
 }
 
-__global__ __launch_bounds__(BLOCK) void field_solve_kernel(
+__global__ __launch_bounds__(SBLOCK) void field_solve_kernel(
     const double* __restrict__ part, const double* __restrict__ E_ext, const double* __restrict__ ke_part,
     double* __restrict__ n_out, double* __restrict__ Ef_out, double* __restrict__ E_out,
     double* __restrict__ phi_out, double* __restrict__ KE_out, double* __restrict__ PE_out,
@@ -336,19 +395,34 @@ __global__ __launch_bounds__(BLOCK) void field_solve_kernel(
   extern __shared__ __align__(16) unsigned char smem_raw[];
   double* sb = reinterpret_cast<double*>(smem_raw);   // b, then G_{j+1/2}
   double* se = sb + a.Ng;                             // E, then phi
-  __shared__ double ws[WAVES];
+  double* sp = se + a.Ng;                             // [SGROUPS][Ng] partial row sums
+  __shared__ double ws[SWAVES];
 
   const int tid = threadIdx.x;
   const int env = blockIdx.x;
   const int Ng = a.Ng;
-  const int m = (Ng + BLOCK - 1) / BLOCK;
+  const int m = (Ng + SBLOCK - 1) / SBLOCK;
   const int lo = min(tid * m, Ng), hi = min(lo + m, Ng);
 
-  // density: sum the slab rows in block order, scale (interpolate.py:16-18), b = n - n0 (pic.py:116)
+  // density: slab rows summed in a fixed order (group g takes rows g, g+4, ...; 4 loads in flight per
+  // lane), scaled (interpolate.py:16-18), b = n - n0 (pic.py:116)
   const double* slab = part + (size_t)env * a.nblk * Ng;
-  for (int j = tid; j < Ng; j += BLOCK) {
-    double s = 0.0;
-    for (int b = 0; b < a.nblk; ++b) s += slab[(size_t)b * Ng + j];
+  const int g = tid >> 8, lane = tid & 255;
+  for (int j = lane; j < Ng; j += 256) {
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int b = g;
+    for (; b + 3 * SGROUPS < a.nblk; b += 4 * SGROUPS) {
+      s0 += slab[(size_t)b * Ng + j];
+      s1 += slab[(size_t)(b + SGROUPS) * Ng + j];
+      s2 += slab[(size_t)(b + 2 * SGROUPS) * Ng + j];
+      s3 += slab[(size_t)(b + 3 * SGROUPS) * Ng + j];
+    }
+    for (; b < a.nblk; b += SGROUPS) s0 += slab[(size_t)b * Ng + j];
+    sp[g * Ng + j] = (s0 + s1) + (s2 + s3);
+  }
+  __syncthreads();
+  for (int j = tid; j < Ng; j += SBLOCK) {
+    double s = (sp[j] + sp[Ng + j]) + (sp[2 * Ng + j] + sp[3 * Ng + j]);
     double nj = s * a.scale;
     if (n_out) n_out[(size_t)env * Ng + j] = nj;
     sb[j] = nj - a.n0;
@@ -363,18 +437,18 @@ __global__ __launch_bounds__(BLOCK) void field_solve_kernel(
   loc = 0.0;
   for (int j = lo; j < hi; ++j) {
     run += sb[j];
-    double g = run * a.dx;
-    sb[j] = g;
-    loc += g;
+    double gj = run * a.dx;
+    sb[j] = gj;
+    loc += gj;
   }
   const double gmean = block_sum(loc, ws) / (double)Ng;   // syncs: all of sb is G now
 
   // E_j = -(G_{j+1/2} + G_{j-1/2}) / 2, plus the external field for force evaluations (util.py:102-103)
   double e2 = 0.0;
-  for (int j = tid; j < Ng; j += BLOCK) {
-    double g = sb[j] - gmean;
+  for (int j = tid; j < Ng; j += SBLOCK) {
+    double gp = sb[j] - gmean;
     double gm = sb[j == 0 ? Ng - 1 : j - 1] - gmean;
-    double E = -0.5 * (g + gm);
+    double E = -0.5 * (gp + gm);
     se[j] = E;
     double Et = E_ext ? E + E_ext[(size_t)env * Ng + j] : E;
     if (Ef_out) Ef_out[(size_t)env * Ng + j] = Et;
@@ -390,7 +464,7 @@ __global__ __launch_bounds__(BLOCK) void field_solve_kernel(
 
   if (KE_out) {
     double k = 0.0;
-    for (int b = tid; b < a.nblk; b += BLOCK) k += ke_part[(size_t)env * a.nblk + b];
+    for (int b = tid; b < a.nblk; b += SBLOCK) k += ke_part[(size_t)env * a.nblk + b];
     k = block_sum(k, ws);
     if (tid == 0) KE_out[env] = 0.5 * k;              // util.py:144
   }
@@ -407,7 +481,7 @@ __global__ __launch_bounds__(BLOCK) void field_solve_kernel(
       run += (sb[j] - gmean) * a.dx;
     }
     const double pmean = block_sum(ploc, ws) / (double)Ng;
-    for (int j = tid; j < Ng; j += BLOCK) phi_out[(size_t)env * Ng + j] = se[j] - pmean;
+    for (int j = tid; j < Ng; j += SBLOCK) phi_out[(size_t)env * Ng + j] = se[j] - pmean;
   }
 }
 
@@ -431,7 +505,7 @@ __global__ __launch_bounds__(BLOCK) void gather_E_kernel(const T* __restrict__ x
     T w[3], xw;
     int j;
     unsigned bad = 0;
-    locate<T, SHAPE>(x[(size_t)env * ld + i], L, dx, Ng, xw, j, w, bad);
+    locate<T, SHAPE>(x[(size_t)env * ld + i], L, dx, T(1) / dx, Ng, xw, j, w, bad);
     E_out[(size_t)env * N + i] = gather_field<T, SHAPE>(Es, j, w);
   }
 }
@@ -446,7 +520,7 @@ __global__ __launch_bounds__(BLOCK) void cic_query_kernel(const T* __restrict__ 
     T w[3], xw;
     int j;
     unsigned bad = 0;
-    locate<T, PIC_CIC>(x[i], L, dx, Ng, xw, j, w, bad);
+    locate<T, PIC_CIC>(x[i], L, dx, T(1) / dx, Ng, xw, j, w, bad);
     if (jl) jl[i] = j;
     if (jr) jr[i] = (j + 1 == Ng) ? 0 : j + 1;
     if (wl) wl[i] = (double)w[0];
@@ -454,13 +528,20 @@ __global__ __launch_bounds__(BLOCK) void cic_query_kernel(const T* __restrict__ 
   }
 }
 
-// dense [env][N] <-> padded [env][ld]
-template <typename T>
-__global__ void repack_kernel(T* __restrict__ dst, const T* __restrict__ src, long long N, long long ld_dst,
-                              long long ld_src) {
-  const int env = blockIdx.y;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (long long)gridDim.x * blockDim.x)
-    dst[(size_t)env * ld_dst + i] = src[(size_t)env * ld_src + i];
+// Streaming ceiling of this box for the sweeps' access shape: read two arrays, write two arrays, 16 B
+// per lane, same grid -- what a sweep would take if it did no arithmetic at all.
+__global__ __launch_bounds__(BLOCK) void stream_probe_kernel(double2* __restrict__ a, double2* __restrict__ b,
+                                                             long long n2, long long chunk2, double scale,
+                                                             int reverse) {
+  const long long bid = reverse ? (long long)gridDim.x - 1 - blockIdx.x : blockIdx.x;
+  long long begin = bid * chunk2;
+  long long end = begin + chunk2 < n2 ? begin + chunk2 : n2;
+  for (long long i = begin + threadIdx.x; i < end; i += BLOCK) {
+    double2 u = a[i], w = b[i];
+    u.x *= scale; u.y *= scale; w.x *= scale; w.y *= scale;
+    a[i] = u;
+    b[i] = w;
+  }
 }
 
 }  // namespace
@@ -484,7 +565,10 @@ struct pic_handle {
   void* x = nullptr;
   void* v = nullptr;
   void* scratch = nullptr;        // [env][ld] staging (eval_field positions, dense<->padded copies)
-  double* part = nullptr;         // [env][nblk][Ng]
+  double* part = nullptr;         // [env][nblk][Ng] deposit of the sweep just run
+  double* part2 = nullptr;        // [env][nblk][Ng] deposit of the NEXT step's q1 (sweeps D / REFRESH)
+  int sweep_parity = 0;           // direction of the next push sweep
+  bool q1_ready = false;          // part2 matches the stored particles, dt and c1: sweep A can be skipped
   double* ke_part = nullptr;      // [env][nblk]
   double* Ef = nullptr;           // field used by the gathers (E + E_ext)
   double* n = nullptr;
@@ -542,7 +626,7 @@ template <typename T, typename A, int SHAPE, int STAGE>
 void launch_sweep_t(pic_handle* h, void* x, void* v, const SweepArgs& a) {
   dim3 grid(h->nblk, h->cfg.num_envs);
   hipLaunchKernelGGL((sweep_kernel<T, A, SHAPE, STAGE>), grid, dim3(BLOCK), h->sweep_lds, h->stream,
-                     static_cast<T*>(x), static_cast<T*>(v), h->Ef, h->part, h->ke_part, h->bad, a);
+                     static_cast<T*>(x), static_cast<T*>(v), h->Ef, h->part, h->part2, h->ke_part, h->bad, a);
 }
 
 template <typename T, typename A, int SHAPE>
@@ -563,20 +647,8 @@ void launch_sweep_i(pic_handle* h, int stage, void* x, void* v, const SweepArgs&
   else launch_sweep_s<T, A, PIC_CIC>(h, stage, x, v, a);
 }
 
-void prof_begin(pic_handle* h, int kind) {
-  if (!h->prof) return;
-  hipEvent_t a, b;
-  hipEventCreate(&a);
-  hipEventCreate(&b);
-  hipEventRecord(a, h->stream);
-  h->ev.push_back(a);
-  h->ev.push_back(b);
-  h->ev_kind.push_back(kind);
-}
-void prof_end(pic_handle* h) {
-  if (!h->prof) return;
-  hipEventRecord(h->ev.back(), h->stream);
-}
+// Per-launch HIP-event brackets on the handle's stream.  Events come from a pool that is only grown
+// (never created inside a timed loop once warm) and recycled by prof_drain.
 void prof_drain(pic_handle* h) {
   for (size_t i = 0; i < h->ev_kind.size(); ++i) {
     float ms = 0.f;
@@ -585,17 +657,40 @@ void prof_drain(pic_handle* h) {
       h->ms_sum[h->ev_kind[i]] += ms;
       h->launches[h->ev_kind[i]] += 1;
     }
-    hipEventDestroy(h->ev[2 * i]);
-    hipEventDestroy(h->ev[2 * i + 1]);
   }
-  h->ev.clear();
   h->ev_kind.clear();
+}
+void prof_reserve(pic_handle* h, size_t pairs) {
+  while (h->ev.size() < 2 * pairs) {
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) break;
+    h->ev.push_back(e);
+  }
+}
+void prof_begin(pic_handle* h, int kind) {
+  if (!h->prof) return;
+  if (h->ev_kind.size() >= 4096) prof_drain(h);
+  const size_t i = h->ev_kind.size();
+  prof_reserve(h, i + 1);
+  hipEventRecord(h->ev[2 * i], h->stream);
+  h->ev_kind.push_back(kind);
+}
+void prof_end(pic_handle* h) {
+  if (!h->prof) return;
+  hipEventRecord(h->ev[2 * (h->ev_kind.size() - 1) + 1], h->stream);
 }
 
 void launch_sweep(pic_handle* h, int stage, void* x, void* v, double c_prev, double c_cur, double d_cur) {
   SweepArgs a;
+  a.c_next = h->cs[0];
   a.N = h->cfg.N; a.ld = h->ld; a.chunk = h->chunk; a.Ng = h->cfg.Ng; a.nblk = h->nblk; a.R = h->R;
+#ifdef PIC_EXP_NOREVERSE
+  a.reverse = 0;
+#else
+  a.reverse = (stage <= ST_D) ? (h->sweep_parity ^= 1) : 0;
+#endif
   a.L = h->cfg.L; a.dx = h->dx; a.dt = h->cfg.dt;
+  a.rdx = h->cfg.particle_dtype == PIC_F64 ? 1.0 / h->dx : (double)(1.0f / (float)h->dx);
   a.c_prev = c_prev; a.c_cur = c_cur; a.d_cur = d_cur;
   prof_begin(h, stage <= ST_D ? stage : 5);
   if (h->cfg.particle_dtype == PIC_F64) launch_sweep_i<double, double>(h, stage, x, v, a);
@@ -605,6 +700,7 @@ void launch_sweep(pic_handle* h, int stage, void* x, void* v, double c_prev, dou
 }
 
 struct SolveOut {
+  const double* slab = nullptr;   // default: h->part
   const double* ext = nullptr;
   const double* ke_part = nullptr;
   double* n = nullptr; double* Ef = nullptr; double* E = nullptr; double* phi = nullptr;
@@ -616,7 +712,8 @@ void launch_solve(pic_handle* h, const SolveOut& o) {
   a.N = h->cfg.N; a.Ng = h->cfg.Ng; a.nblk = h->nblk; a.L = h->cfg.L; a.dx = h->dx; a.n0 = h->cfg.n0;
   a.scale = h->scale; a.N_over_L = (double)h->cfg.N / h->cfg.L;
   prof_begin(h, 4);
-  hipLaunchKernelGGL(field_solve_kernel, dim3(h->cfg.num_envs), dim3(BLOCK), h->solve_lds, h->stream, h->part, o.ext,
+  hipLaunchKernelGGL(field_solve_kernel, dim3(h->cfg.num_envs), dim3(SBLOCK), h->solve_lds, h->stream,
+                     o.slab ? o.slab : h->part, o.ext,
                      o.ke_part, o.n, o.Ef, o.E, o.phi, o.KE, o.PE, o.PEr, a);
   prof_end(h);
 }
@@ -628,6 +725,7 @@ int refresh_fields(pic_handle* h) {
   o.KE = h->KE; o.PE = h->PE; o.PEr = h->PEr;
   launch_solve(h, o);
   HIPCHK(h, hipGetLastError());
+  h->q1_ready = true;   // ST_REFRESH also deposited the next step's q1 into part2
   return PIC_OK;
 }
 
@@ -709,13 +807,13 @@ int pic_create(const pic_config* cfg, pic_handle** out) {
   h->nblk = (int)nblk;
 
   const size_t stride = (size_t)cfg->Ng + 2;
-  h->R = 4;
-  while (h->R > 1 && h->R * stride * h->asz + stride * h->esz > 40 * 1024) h->R >>= 1;
-  h->sweep_lds = h->R * stride * h->asz + stride * h->esz;
-  h->solve_lds = 2 * (size_t)cfg->Ng * sizeof(double);
-  if (h->sweep_lds > 150 * 1024 || h->solve_lds > 150 * 1024) {
+  h->R = 4;   // LDS: 2 R meshes (sweep D deposits two) + the field tile
+  while (h->R > 1 && 2 * h->R * stride * h->asz + stride * h->esz > 40 * 1024) h->R >>= 1;
+  h->sweep_lds = 2 * h->R * stride * h->asz + stride * h->esz;
+  h->solve_lds = (2 + SGROUPS) * (size_t)cfg->Ng * sizeof(double);
+  if (h->sweep_lds > 64 * 1024 || h->solve_lds > 150 * 1024) {
     delete h;
-    return fail(nullptr, PIC_EINVAL, "pic_create: Ng too large for the LDS-resident mesh (max ~9000 cells)");
+    return fail(nullptr, PIC_EINVAL, "pic_create: Ng too large for the LDS-resident mesh (max 2700 cells)");
   }
 
 #define CREATE_CHK(call)                                                                      \
@@ -729,6 +827,9 @@ int pic_create(const pic_config* cfg, pic_handle** out) {
   } while (0)
 
   CREATE_CHK(hipSetDevice(cfg->device_id));
+  if (h->solve_lds > 64 * 1024)
+    CREATE_CHK(hipFuncSetAttribute((const void*)field_solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)h->solve_lds));
   CREATE_CHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
   const size_t pbytes = (size_t)cfg->num_envs * h->ld * h->esz;
   const size_t gbytes = (size_t)cfg->num_envs * cfg->Ng * sizeof(double);
@@ -737,6 +838,7 @@ int pic_create(const pic_config* cfg, pic_handle** out) {
   CREATE_CHK(hipMemsetAsync(h->x, 0, pbytes, h->stream));
   CREATE_CHK(hipMemsetAsync(h->v, 0, pbytes, h->stream));
   CREATE_CHK(hipMalloc((void**)&h->part, gbytes * h->nblk));
+  CREATE_CHK(hipMalloc((void**)&h->part2, gbytes * h->nblk));
   CREATE_CHK(hipMalloc((void**)&h->ke_part, (size_t)cfg->num_envs * h->nblk * sizeof(double)));
   CREATE_CHK(hipMemsetAsync(h->ke_part, 0, (size_t)cfg->num_envs * h->nblk * sizeof(double), h->stream));
   double** grids[] = {&h->Ef, &h->n, &h->E_mesh, &h->phi, &h->ext, &h->aux_n, &h->aux_E};
@@ -762,7 +864,8 @@ int pic_destroy(pic_handle* h) {
   hipSetDevice(h->cfg.device_id);
   if (h->stream) hipStreamSynchronize(h->stream);
   prof_drain(h);
-  void* bufs[] = {h->x, h->v, h->scratch, h->part, h->ke_part, h->Ef, h->n, h->E_mesh, h->phi, h->ext,
+  for (hipEvent_t e : h->ev) hipEventDestroy(e);
+  void* bufs[] = {h->x, h->v, h->scratch, h->part, h->part2, h->ke_part, h->Ef, h->n, h->E_mesh, h->phi, h->ext,
                   h->aux_n, h->aux_E, h->aux_pe, h->KE, h->PE, h->PEr, h->bad};
   for (void* b : bufs)
     if (b) hipFree(b);
@@ -787,6 +890,7 @@ int pic_set_particles(pic_handle* h, const void* x, const void* v, int mem_kind)
   if (rc) return rc;
   if (mem_kind == PIC_HOST) HIPCHK(h, hipStreamSynchronize(h->stream));
   h->has_state = true;
+  h->q1_ready = false;
   return PIC_OK;
 }
 
@@ -824,8 +928,14 @@ int pic_step(pic_handle* h, const double* E_ext, int mem_kind, int nsteps) {
   for (int s = 0; s < nsteps; ++s) {
     SolveOut f;           // force evaluation: only the gather field is needed
     f.ext = ext; f.Ef = h->Ef;
-    launch_sweep(h, ST_A, h->x, h->v, 0.0, c[0], 0.0);
-    launch_solve(h, f);
+    if (h->q1_ready) {    // the previous sweep D / reset already deposited q1 = x + (c1 v) dt
+      SolveOut f1 = f;
+      f1.slab = h->part2;
+      launch_solve(h, f1);
+    } else {
+      launch_sweep(h, ST_A, h->x, h->v, 0.0, c[0], 0.0);
+      launch_solve(h, f);
+    }
     launch_sweep(h, ST_B, h->x, h->v, c[0], c[1], d[1]);
     launch_solve(h, f);
     launch_sweep(h, ST_C, h->x, h->v, 0.0, c[2], d[2]);
@@ -835,6 +945,7 @@ int pic_step(pic_handle* h, const double* E_ext, int mem_kind, int nsteps) {
     o.ke_part = h->ke_part; o.n = h->n; o.E = h->E_mesh; o.phi = h->phi;
     o.KE = h->KE; o.PE = h->PE; o.PEr = h->PEr;
     launch_solve(h, o);
+    h->q1_ready = true;
   }
   HIPCHK(h, hipGetLastError());
   return PIC_OK;
@@ -981,6 +1092,40 @@ int pic_eval_field(pic_handle* h, const void* x, int mem_kind, const double* E_e
   return PIC_OK;
 }
 
+int pic_stream_probe(pic_handle* h, int repeats, double* gbytes_per_s) {
+  if (!h || !gbytes_per_s || repeats < 1) return fail(h, PIC_EINVAL, "pic_stream_probe: bad argument");
+  HIPCHK(h, hipSetDevice(h->cfg.device_id));
+  size_t pbytes = (size_t)h->cfg.num_envs * h->ld * h->esz;
+  if (const char* mb = getenv("PICSTEP_PROBE_MB")) pbytes = (size_t)atoll(mb) << 20;   // experiment knob
+  void *a = nullptr, *b = nullptr;
+  HIPCHK(h, hipMalloc(&a, pbytes));
+  if (hipMalloc(&b, pbytes) != hipSuccess) { hipFree(a); return fail(h, PIC_ENOMEM, "pic_stream_probe: hipMalloc"); }
+  hipMemsetAsync(a, 0, pbytes, h->stream);
+  hipMemsetAsync(b, 0, pbytes, h->stream);
+  const long long n2 = (long long)(pbytes / sizeof(double2));
+  long long nb = n2 / ((long long)BLOCK * 31);       // ~31 tiles per lane, like a sweep workgroup
+  if (nb < 256) nb = 256;
+  const long long chunk2 = (n2 + nb - 1) / nb;
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0);
+  hipEventCreate(&e1);
+  hipLaunchKernelGGL(stream_probe_kernel, dim3((unsigned)nb), dim3(BLOCK), 0, h->stream, (double2*)a, (double2*)b, n2, chunk2, 1.0, 1);
+  hipEventRecord(e0, h->stream);
+  for (int r = 0; r < repeats; ++r)
+    hipLaunchKernelGGL(stream_probe_kernel, dim3((unsigned)nb), dim3(BLOCK), 0, h->stream, (double2*)a, (double2*)b, n2, chunk2, 1.0, r & 1);
+  hipEventRecord(e1, h->stream);
+  hipError_t e = hipEventSynchronize(e1);
+  float ms = 0.f;
+  if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+  hipEventDestroy(e0);
+  hipEventDestroy(e1);
+  hipFree(a);
+  hipFree(b);
+  if (e != hipSuccess) return fail(h, PIC_EHIP, std::string("pic_stream_probe: ") + hipGetErrorString(e));
+  *gbytes_per_s = 4.0 * (double)pbytes * repeats / (ms * 1e-3) / 1e9;
+  return PIC_OK;
+}
+
 int pic_profile(pic_handle* h, int enable) {
   if (!h) return PIC_EINVAL;
   HIPCHK(h, hipSetDevice(h->cfg.device_id));
@@ -988,6 +1133,7 @@ int pic_profile(pic_handle* h, int enable) {
   prof_drain(h);
   h->prof = enable != 0;
   if (enable) {
+    prof_reserve(h, 1024);
     std::memset(h->ms_sum, 0, sizeof(h->ms_sum));
     std::memset(h->launches, 0, sizeof(h->launches));
   }

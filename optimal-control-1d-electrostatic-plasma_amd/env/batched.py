@@ -78,6 +78,10 @@ class BatchedPIC:
     def eval_field(self, x, E_ext=None):
         return self._h.eval_field(x, E_ext)
 
+    def stream_probe(self, repeats=10):
+        """GB/s of a read-2-arrays / write-2-arrays copy with the sweeps' grid on this device."""
+        return self._h.stream_probe(repeats)
+
     def bad_count(self):
         return self._h.bad_count()
 

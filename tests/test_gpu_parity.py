@@ -277,6 +277,33 @@ def test_nsteps_in_one_call_equals_repeated_calls(oc, po):
     assert circ_err(xa[0], xa[1][::-1], L) / L < 1e-12 and rel_err(a.fields()[1][0], a.fields()[1][1]) < 1e-11
 
 
+def test_sweep_A_is_skipped_only_when_its_deposit_is_already_there(oc, po):
+    """Sweep D / reset also deposit the next step's q1, so sweep A normally never runs; loading
+    particles without a refresh invalidates that deposit and must fall back to sweep A."""
+    N, Ng, L = 40000, 256, 50.0
+    x0, v0 = po.synthetic_bump_on_tail(N, L, seed=21)
+    a = oc._abi.Handle(N, Ng, 1, L, 1.0, 0.05)
+    b = oc._abi.Handle(N, Ng, 1, L, 1.0, 0.05)
+    a.reset(x0[None], v0[None])
+    b.reset(x0[None], v0[None])
+    a.profile(True)
+    b.profile(True)
+    for _ in range(3):
+        a.step()
+        xb, vb = b.particles()
+        b.set_particles(xb, vb)         # same state, but the q1 deposit is now stale -> sweep A path
+        b.step()
+    (xa, va), (xb, vb) = a.particles(), b.particles()
+    assert circ_err(xa, xb, L) / L < 1e-13 and rel_err(va, vb) < 1e-13
+    assert rel_err(a.fields()[1], b.fields()[1]) < 1e-11
+    pa, pb = a.profile_read(), b.profile_read()
+    assert "sweep_A" not in pa and pb["sweep_A"][1] == 3
+    ref = po.OraclePIC(x0, v0, Ng, L=L, dt=0.05, perturb=False, faithful=False)
+    for _ in range(3):
+        ref.update_state(None)
+    assert circ_err(xa[0], ref.x, L) / L < 1e-13 and rel_err(va[0], ref.v) < 1e-13
+
+
 def test_full_size_invariants_and_one_step_parity(oc, po):
     """BASELINE config-2 sized environments (N = 1e6, Ng = 256): one-step parity with the oracle on
     environment 0, then size-independent properties over 20 steps."""
