@@ -1,3 +1,4 @@
 from .pic import PIC
 from .batched import BatchedPIC
 from .dist import TwoStream, BumpOnTail
+from .sharded import ShardedPIC, shard_range

@@ -1,7 +1,7 @@
 """Batched rollout environments: `num_envs` independent PIC systems stepped by one
 libpicstep handle on one MI355X (BASELINE configs 2-5).  Nothing couples the
 environments inside a step; across GPUs they are sharded rank-wise
-(`..parallel.ShardedPIC`), never split.
+(`.sharded.ShardedPIC`), never split.
 """
 from typing import Optional
 

@@ -1,0 +1,96 @@
+"""Environment sharding across the GPUs of one node: one process per GPU, each owning a contiguous
+block of the rollout environments in its own `BatchedPIC` handle.
+
+Nothing couples environments inside a step, so there is NO collective on the step path.  The only
+exchanges are (i) the all-gather of per-environment returns / rewards (<= 1 KB per rank, latency
+bound on xGMI) and (ii) optionally the broadcast of actions from the rank that runs the policy.
+`torch.distributed` backend "nccl" is RCCL on ROCm; the CPU tests run the same code over "gloo".
+"""
+from typing import Callable, Optional
+
+import numpy as np
+
+
+def shard_range(rank: int, world: int, total_envs: int):
+    """Contiguous block of environments owned by `rank` (sizes differ by at most one)."""
+    base, extra = divmod(total_envs, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+class ShardedPIC:
+    def __init__(self, total_envs: int, N: int, N_mesh: int, env_factory: Optional[Callable] = None,
+                 device: Optional[int] = None, **env_kwargs):
+        import torch.distributed as dist
+
+        self.dist = dist
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self.rank = dist.get_rank() if dist.is_initialized() else 0
+        self.total_envs = int(total_envs)
+        self.lo, self.hi = shard_range(self.rank, self.world, self.total_envs)
+        self.num_local = self.hi - self.lo
+        self.counts = [shard_range(r, self.world, self.total_envs) for r in range(self.world)]
+        if env_factory is None:
+            from .batched import BatchedPIC
+
+            def env_factory(num_envs, N, N_mesh, **kw):
+                return BatchedPIC(num_envs, N, N_mesh, **kw)
+        if device is not None:
+            env_kwargs["device"] = device
+        self.env = env_factory(self.num_local, N, N_mesh, **env_kwargs)
+        self.N, self.N_mesh = N, N_mesh
+
+    def _backend_device(self):
+        import torch
+        if self.dist.is_initialized() and self.dist.get_backend() == "nccl":
+            return torch.device("cuda", torch.cuda.current_device())
+        return torch.device("cpu")
+
+    def local_slice(self, global_array):
+        """Rows of a [total_envs, ...] array that belong to this rank."""
+        return np.asarray(global_array)[self.lo:self.hi]
+
+    def reset(self, x0, v0, is_global: bool = False):
+        if is_global:
+            x0, v0 = self.local_slice(x0), self.local_slice(v0)
+        self.env.reset(x0, v0)
+
+    def step(self, E_external=None, nsteps: int = 1, is_global: bool = False):
+        if E_external is not None and is_global:
+            E_external = self.local_slice(E_external)
+        self.env.step(E_external, nsteps)
+
+    def broadcast_actions(self, actions, src: int = 0):
+        """[total_envs, A] actions decided on `src` -> every rank (then `local_slice`)."""
+        import torch
+        t = torch.as_tensor(np.ascontiguousarray(actions, dtype=np.float64), device=self._backend_device())
+        if self.world > 1:
+            self.dist.broadcast(t, src=src)
+        return t.cpu().numpy()
+
+    def gather(self, local_values):
+        """All-gather of a per-environment quantity: [num_local, ...] -> [total_envs, ...] in global
+        environment order, identical on every rank."""
+        import torch
+        loc = np.ascontiguousarray(local_values, dtype=np.float64)
+        if self.world == 1:
+            return loc
+        dev = self._backend_device()
+        tail = loc.shape[1:]
+        pad = max(hi - lo for lo, hi in self.counts)
+        buf = torch.zeros((pad,) + tail, dtype=torch.float64, device=dev)
+        buf[: self.num_local] = torch.as_tensor(loc, device=dev)
+        out = [torch.empty_like(buf) for _ in range(self.world)]
+        self.dist.all_gather(out, buf)
+        return np.concatenate([o[: hi - lo].cpu().numpy() for o, (lo, hi) in zip(out, self.counts)], axis=0)
+
+    def gather_returns(self):
+        """Per-environment reward of the current state, max(1 - PE_r, 0) (reward.py:72), for all ranks."""
+        return self.gather(self.env.rewards())
+
+    def gather_energies(self):
+        ke, pe, per = self.env.energies()
+        return self.gather(np.stack([ke, pe, per], axis=1))
+
+    def close(self):
+        self.env.close()
