@@ -59,6 +59,7 @@ struct SweepArgs {
   int nblk;           // workgroups per env
   int R;              // LDS mesh replicas per workgroup (1, 2 or 4)
   int reverse;        // walk environments and chunks from the far end (alternates sweep to sweep)
+  int env0;           // first environment of this launch (launches may cover a group of environments)
   double L, dx, rdx, dt;   // rdx = 1/dx (for float particles: 1/(float)dx)
   double c_prev, c_cur, d_cur, c_next;
 };
@@ -68,6 +69,7 @@ struct SolveArgs {
   int Ng;
   int nblk;
   double L, dx, n0;
+  int env0;            // first environment of this launch
   double scale;        // n0 * L / N / dx, evaluated left to right as interpolate.py:18
   double N_over_L;
 };
@@ -79,7 +81,20 @@ struct SolveArgs {
 // fmod-based np.mod (Sterbenz: q-L is exact for L <= q < 2L).
 // ---------------------------------------------------------------------------------------------
 template <typename T>
+__device__ __noinline__ T wrap_periodic_far(T q, T L) {   // |q| beyond one box length: rare
+  T r = fmod(q, L);
+  if (r < T(0)) {
+    r += L;
+    if (r >= L) r = T(0);
+  } else if (r == T(0)) {
+    r = T(0);   // np.mod returns +0 for a zero remainder
+  }
+  return r;
+}
+
+template <typename T>
 __device__ __forceinline__ T wrap_periodic(T q, T L) {
+#ifdef PIC_EXP_BRANCHY_WRAP
   T r;
   if (q >= T(0) && q < L) {
     r = q;
@@ -89,15 +104,18 @@ __device__ __forceinline__ T wrap_periodic(T q, T L) {
     r = q + L;
     if (r >= L) r = T(0);
   } else {
-    r = fmod(q, L);
-    if (r < T(0)) {
-      r += L;
-      if (r >= L) r = T(0);
-    } else if (r == T(0)) {
-      r = T(0);   // np.mod returns +0 for a zero remainder
-    }
+    r = wrap_periodic_far(q, L);
   }
   return r;
+#else
+  // the three near ranges as selects (a particle moves a small fraction of L per sub-stage)
+  T up = q + L;                       // q in [-L, 0)
+  up = (up >= L) ? T(0) : up;         // tiny negative q: q + L rounds to L, the second mod gives 0
+  T r = (q < T(0)) ? up : q;
+  r = (q >= L) ? q - L : r;           // q in [L, 2L): exact (Sterbenz)
+  if (__builtin_expect(!(q >= -L && q < L + L), 0)) r = wrap_periodic_far(q, L);
+  return r;
+#endif
 }
 
 // a / dx for the loop-invariant divisor dx, with rdx = 1/dx rounded once on the host: one Newton
@@ -167,6 +185,12 @@ __device__ __forceinline__ void deposit(A* __restrict__ acc, int j, const T (&w)
 #endif
 }
 
+#ifndef PIC_PIPE
+#define PIC_PIPE 0      // tiles prefetched ahead of the one being pushed (experiment; the compiler sinks them)
+#endif
+#ifndef PIC_TILES
+#define PIC_TILES 1     // 16-B tiles per lane per loop iteration
+#endif
 #define PIC_LOAD(p) (*(p))
 #define PIC_STORE(v, p) (*(p) = (v))
 
@@ -265,7 +289,7 @@ __global__ __launch_bounds__(BLOCK) void sweep_kernel(T* __restrict__ x, T* __re
   const int tid = threadIdx.x;
   // Consecutive sweeps walk memory in opposite directions: what the previous sweep wrote last (still
   // in the 256 MB Infinity Cache) is what this one reads first.
-  const int env = a.reverse ? (int)gridDim.y - 1 - (int)blockIdx.y : (int)blockIdx.y;
+  const int env = a.env0 + (a.reverse ? (int)gridDim.y - 1 - (int)blockIdx.y : (int)blockIdx.y);
   const int blk = a.reverse ? (int)gridDim.x - 1 - (int)blockIdx.x : (int)blockIdx.x;
 
   for (int i = tid; i < nacc; i += BLOCK) acc_all[i] = A(0);
@@ -295,7 +319,64 @@ __global__ __launch_bounds__(BLOCK) void sweep_kernel(T* __restrict__ x, T* __re
   double ke = 0.0;
   unsigned bad = 0u;
   long long i = begin + (long long)tid * VEC;
-  for (; i + VEC <= end; i += step) {
+#if PIC_PIPE == 0
+  // PIC_TILES tiles per lane per iteration: all their loads are issued before the first particle is
+  // pushed, so a wave keeps PIC_TILES x 2 KB of requests in flight while it waits.
+#ifdef PIC_EXP_STAMP   // diagnostic build: wall-clock (10 ns ticks) spent waiting for loads vs pushing, per wave 0
+  unsigned long long st_mem = 0, st_cmp = 0, st_n = 0;
+#endif
+  for (; i + (long long)(PIC_TILES - 1) * step + VEC <= end; i += (long long)PIC_TILES * step) {
+    V xv[PIC_TILES], vv[PIC_TILES];
+#ifdef PIC_EXP_STAMP
+    __builtin_amdgcn_sched_barrier(0);
+    const unsigned long long st0 = wall_clock64();
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+#pragma unroll
+    for (int t = 0; t < PIC_TILES; ++t) {
+      xv[t] = PIC_LOAD(reinterpret_cast<const V*>(xe + i + (long long)t * step));
+      vv[t] = V{};
+      if (kReadV) vv[t] = PIC_LOAD(reinterpret_cast<const V*>(ve + i + (long long)t * step));
+    }
+#ifdef PIC_EXP_STAMP
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long st1 = wall_clock64();
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+#pragma unroll
+    for (int t = 0; t < PIC_TILES; ++t) {
+      T* xs = reinterpret_cast<T*>(&xv[t]);
+      T* vs = reinterpret_cast<T*>(&vv[t]);
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) {
+        T pv = kReadV ? vs[k] : T(0);
+        push_one<T, A, SHAPE, STAGE>(xs[k], pv, Es, acc, acc2, L, dx, rdx, dt, c_prev, c_cur, d_cur, c_next, Ng, ke, bad);
+        if (kReadV) vs[k] = pv;
+      }
+      if (kStore) {
+        PIC_STORE(xv[t], reinterpret_cast<V*>(xe + i + (long long)t * step));
+        if (kStoreV) PIC_STORE(vv[t], reinterpret_cast<V*>(ve + i + (long long)t * step));
+      }
+    }
+#ifdef PIC_EXP_STAMP
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const unsigned long long st2 = wall_clock64();
+    __builtin_amdgcn_sched_barrier(0);
+    st_mem += st1 - st0;
+    st_cmp += st2 - st1;
+    st_n += 1;
+#endif
+  }
+#ifdef PIC_EXP_STAMP
+  if (tid == 0 && (STAGE == ST_C)) {
+    atomicAdd(&bad_count[1], st_mem);
+    atomicAdd(&bad_count[2], st_cmp);
+    atomicAdd(&bad_count[3], st_n);
+  }
+#endif
+  for (; i + VEC <= end; i += step) {          // leftover whole tiles
     V xv = PIC_LOAD(reinterpret_cast<const V*>(xe + i));
     V vv = {};
     if (kReadV) vv = PIC_LOAD(reinterpret_cast<const V*>(ve + i));
@@ -312,6 +393,53 @@ __global__ __launch_bounds__(BLOCK) void sweep_kernel(T* __restrict__ x, T* __re
       if (kStoreV) PIC_STORE(vv, reinterpret_cast<V*>(ve + i));
     }
   }
+#else
+  // Software pipeline (double buffer).  The next tile's loads are issued by inline asm BEFORE the current
+  // tile is pushed: written as plain C loads, hipcc proves they cannot alias the stores and sinks them back
+  // down to their use, so memory wait and push never overlap (stamped: 2.0 us + 1.8 us per iteration, all
+  // waves of a SIMD in lockstep).  hipcc does not count asm loads in its own s_waitcnt, so the wait is
+  // explicit: in issue order the younger VMEM operations at that point are exactly this iteration's stores
+  // (kNumStores), hence vmcnt(kNumStores).  The "+v" ties keep every use of the prefetched registers behind
+  // the wait (cdna_hip_programming.md 5.7).
+  constexpr int kNumStores = kStore ? (kStoreV ? 2 : 1) : 0;
+  bool have = (i + VEC <= end);
+  V cx = {}, cv = {};
+  if (have) {
+    cx = PIC_LOAD(reinterpret_cast<const V*>(xe + i));
+    if (kReadV) cv = PIC_LOAD(reinterpret_cast<const V*>(ve + i));
+  }
+  while (have) {
+    const long long in = i + step;
+    const bool hn = (in + VEC <= end);
+    V nx = {}, nv = {};
+    if (hn) {
+      if (kReadV)
+        asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %3, off"
+                     : "=&v"(nx), "=&v"(nv) : "v"(xe + in), "v"(ve + in) : "memory");
+      else
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(nx) : "v"(xe + in) : "memory");
+    }
+    T* xs = reinterpret_cast<T*>(&cx);
+    T* vs = reinterpret_cast<T*>(&cv);
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+      T pv = kReadV ? vs[k] : T(0);
+      push_one<T, A, SHAPE, STAGE>(xs[k], pv, Es, acc, acc2, L, dx, rdx, dt, c_prev, c_cur, d_cur, c_next, Ng, ke, bad);
+      if (kReadV) vs[k] = pv;
+    }
+    if (kStore) {
+      PIC_STORE(cx, reinterpret_cast<V*>(xe + i));
+      if (kStoreV) PIC_STORE(cv, reinterpret_cast<V*>(ve + i));
+    }
+    if (kNumStores == 2) asm volatile("s_waitcnt vmcnt(2)" : "+v"(nx), "+v"(nv) : : "memory");
+    else if (kNumStores == 1) asm volatile("s_waitcnt vmcnt(1)" : "+v"(nx), "+v"(nv) : : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" : "+v"(nx), "+v"(nv) : : "memory");
+    cx = nx;
+    cv = nv;
+    i = in;
+    have = hn;
+  }
+#endif
   for (long long k = i; k < end; ++k) {       // ragged tail (fewer than VEC particles left for this lane)
     T xq = xe[k];
     T pv = kReadV ? ve[k] : T(0);
@@ -399,7 +527,7 @@ __global__ __launch_bounds__(SBLOCK) void field_solve_kernel(
   __shared__ double ws[SWAVES];
 
   const int tid = threadIdx.x;
-  const int env = blockIdx.x;
+  const int env = a.env0 + blockIdx.x;
   const int Ng = a.Ng;
   const int m = (Ng + SBLOCK - 1) / SBLOCK;
   const int lo = min(tid * m, Ng), hi = min(lo + m, Ng);
@@ -532,13 +660,17 @@ __global__ __launch_bounds__(BLOCK) void cic_query_kernel(const T* __restrict__ 
 // per lane, same grid -- what a sweep would take if it did no arithmetic at all.
 __global__ __launch_bounds__(BLOCK) void stream_probe_kernel(double2* __restrict__ a, double2* __restrict__ b,
                                                              long long n2, long long chunk2, double scale,
-                                                             int reverse) {
+                                                             int reverse, int work) {
   const long long bid = reverse ? (long long)gridDim.x - 1 - blockIdx.x : blockIdx.x;
   long long begin = bid * chunk2;
   long long end = begin + chunk2 < n2 ? begin + chunk2 : n2;
   for (long long i = begin + threadIdx.x; i < end; i += BLOCK) {
     double2 u = a[i], w = b[i];
     u.x *= scale; u.y *= scale; w.x *= scale; w.y *= scale;
+    for (int k = 0; k < work; ++k) {   // experiment: dependent fp64 work between the load and the store
+      u.x = fma(u.x, scale, w.x * 1e-300); w.x = fma(w.x, scale, u.y * 1e-300);
+      u.y = fma(u.y, scale, w.y * 1e-300); w.y = fma(w.y, scale, u.x * 1e-300);
+    }
     a[i] = u;
     b[i] = w;
   }
@@ -562,6 +694,13 @@ struct pic_handle {
   double dx = 0, scale = 0;
   double cs[4]{}, ds[4]{};
   hipStream_t stream = nullptr;
+  // Cache-resident schedule: pic_step walks the environments in groups whose particles fit the
+  // Infinity Cache, each group running all its sweeps back to back on one of `wstreams`.
+  std::vector<hipStream_t> wstreams;
+  std::vector<hipEvent_t> join_ev;
+  hipEvent_t fork_ev = nullptr;
+  int group_envs = 0;             // 0 = no grouping (every launch covers all environments)
+  bool group_major = true;        // all nsteps of a group before the next group (else step by step)
   void* x = nullptr;
   void* v = nullptr;
   void* scratch = nullptr;        // [env][ld] staging (eval_field positions, dense<->padded copies)
@@ -622,29 +761,36 @@ void yoshida_coefficients(double (&c)[4], double (&d)[4]) {
   d[2] = w0;
 }
 
+// where a launch goes: stream + the block of environments it covers
+struct Lane {
+  hipStream_t stream;
+  int env0, nenv;
+  int parity;       // direction of this lane's next push sweep
+};
+
 template <typename T, typename A, int SHAPE, int STAGE>
-void launch_sweep_t(pic_handle* h, void* x, void* v, const SweepArgs& a) {
-  dim3 grid(h->nblk, h->cfg.num_envs);
-  hipLaunchKernelGGL((sweep_kernel<T, A, SHAPE, STAGE>), grid, dim3(BLOCK), h->sweep_lds, h->stream,
+void launch_sweep_t(pic_handle* h, const Lane& ln, void* x, void* v, const SweepArgs& a) {
+  dim3 grid(h->nblk, ln.nenv);
+  hipLaunchKernelGGL((sweep_kernel<T, A, SHAPE, STAGE>), grid, dim3(BLOCK), h->sweep_lds, ln.stream,
                      static_cast<T*>(x), static_cast<T*>(v), h->Ef, h->part, h->part2, h->ke_part, h->bad, a);
 }
 
 template <typename T, typename A, int SHAPE>
-void launch_sweep_s(pic_handle* h, int stage, void* x, void* v, const SweepArgs& a) {
+void launch_sweep_s(pic_handle* h, const Lane& ln, int stage, void* x, void* v, const SweepArgs& a) {
   switch (stage) {
-    case ST_A: launch_sweep_t<T, A, SHAPE, ST_A>(h, x, v, a); break;
-    case ST_B: launch_sweep_t<T, A, SHAPE, ST_B>(h, x, v, a); break;
-    case ST_C: launch_sweep_t<T, A, SHAPE, ST_C>(h, x, v, a); break;
-    case ST_D: launch_sweep_t<T, A, SHAPE, ST_D>(h, x, v, a); break;
-    case ST_REFRESH: launch_sweep_t<T, A, SHAPE, ST_REFRESH>(h, x, v, a); break;
-    default: launch_sweep_t<T, A, SHAPE, ST_PROBE>(h, x, v, a); break;
+    case ST_A: launch_sweep_t<T, A, SHAPE, ST_A>(h, ln, x, v, a); break;
+    case ST_B: launch_sweep_t<T, A, SHAPE, ST_B>(h, ln, x, v, a); break;
+    case ST_C: launch_sweep_t<T, A, SHAPE, ST_C>(h, ln, x, v, a); break;
+    case ST_D: launch_sweep_t<T, A, SHAPE, ST_D>(h, ln, x, v, a); break;
+    case ST_REFRESH: launch_sweep_t<T, A, SHAPE, ST_REFRESH>(h, ln, x, v, a); break;
+    default: launch_sweep_t<T, A, SHAPE, ST_PROBE>(h, ln, x, v, a); break;
   }
 }
 
 template <typename T, typename A>
-void launch_sweep_i(pic_handle* h, int stage, void* x, void* v, const SweepArgs& a) {
-  if (h->cfg.interpol == PIC_TSC) launch_sweep_s<T, A, PIC_TSC>(h, stage, x, v, a);
-  else launch_sweep_s<T, A, PIC_CIC>(h, stage, x, v, a);
+void launch_sweep_i(pic_handle* h, const Lane& ln, int stage, void* x, void* v, const SweepArgs& a) {
+  if (h->cfg.interpol == PIC_TSC) launch_sweep_s<T, A, PIC_TSC>(h, ln, stage, x, v, a);
+  else launch_sweep_s<T, A, PIC_CIC>(h, ln, stage, x, v, a);
 }
 
 // Per-launch HIP-event brackets on the handle's stream.  Events come from a pool that is only grown
@@ -667,36 +813,39 @@ void prof_reserve(pic_handle* h, size_t pairs) {
     h->ev.push_back(e);
   }
 }
-void prof_begin(pic_handle* h, int kind) {
+void prof_begin(pic_handle* h, hipStream_t st, int kind) {
   if (!h->prof) return;
-  if (h->ev_kind.size() >= 4096) prof_drain(h);
+  if (h->ev_kind.size() >= 16384) prof_drain(h);
   const size_t i = h->ev_kind.size();
   prof_reserve(h, i + 1);
-  hipEventRecord(h->ev[2 * i], h->stream);
+  hipEventRecord(h->ev[2 * i], st);
   h->ev_kind.push_back(kind);
 }
-void prof_end(pic_handle* h) {
+void prof_end(pic_handle* h, hipStream_t st) {
   if (!h->prof) return;
-  hipEventRecord(h->ev[2 * (h->ev_kind.size() - 1) + 1], h->stream);
+  hipEventRecord(h->ev[2 * (h->ev_kind.size() - 1) + 1], st);
 }
 
-void launch_sweep(pic_handle* h, int stage, void* x, void* v, double c_prev, double c_cur, double d_cur) {
+Lane whole(pic_handle* h) { return Lane{h->stream, 0, h->cfg.num_envs, 0}; }
+
+void launch_sweep(pic_handle* h, Lane& ln, int stage, void* x, void* v, double c_prev, double c_cur, double d_cur) {
   SweepArgs a;
   a.c_next = h->cs[0];
+  a.env0 = ln.env0;
   a.N = h->cfg.N; a.ld = h->ld; a.chunk = h->chunk; a.Ng = h->cfg.Ng; a.nblk = h->nblk; a.R = h->R;
 #ifdef PIC_EXP_NOREVERSE
   a.reverse = 0;
 #else
-  a.reverse = (stage <= ST_D) ? (h->sweep_parity ^= 1) : 0;
+  a.reverse = (stage <= ST_D) ? (ln.parity ^= 1) : 0;
 #endif
   a.L = h->cfg.L; a.dx = h->dx; a.dt = h->cfg.dt;
   a.rdx = h->cfg.particle_dtype == PIC_F64 ? 1.0 / h->dx : (double)(1.0f / (float)h->dx);
   a.c_prev = c_prev; a.c_cur = c_cur; a.d_cur = d_cur;
-  prof_begin(h, stage <= ST_D ? stage : 5);
-  if (h->cfg.particle_dtype == PIC_F64) launch_sweep_i<double, double>(h, stage, x, v, a);
-  else if (h->cfg.accum_dtype == PIC_F64) launch_sweep_i<float, double>(h, stage, x, v, a);
-  else launch_sweep_i<float, float>(h, stage, x, v, a);
-  prof_end(h);
+  prof_begin(h, ln.stream, stage <= ST_D ? stage : 5);
+  if (h->cfg.particle_dtype == PIC_F64) launch_sweep_i<double, double>(h, ln, stage, x, v, a);
+  else if (h->cfg.accum_dtype == PIC_F64) launch_sweep_i<float, double>(h, ln, stage, x, v, a);
+  else launch_sweep_i<float, float>(h, ln, stage, x, v, a);
+  prof_end(h, ln.stream);
 }
 
 struct SolveOut {
@@ -707,23 +856,25 @@ struct SolveOut {
   double* KE = nullptr; double* PE = nullptr; double* PEr = nullptr;
 };
 
-void launch_solve(pic_handle* h, const SolveOut& o) {
+void launch_solve(pic_handle* h, const Lane& ln, const SolveOut& o) {
   SolveArgs a;
+  a.env0 = ln.env0;
   a.N = h->cfg.N; a.Ng = h->cfg.Ng; a.nblk = h->nblk; a.L = h->cfg.L; a.dx = h->dx; a.n0 = h->cfg.n0;
   a.scale = h->scale; a.N_over_L = (double)h->cfg.N / h->cfg.L;
-  prof_begin(h, 4);
-  hipLaunchKernelGGL(field_solve_kernel, dim3(h->cfg.num_envs), dim3(SBLOCK), h->solve_lds, h->stream,
+  prof_begin(h, ln.stream, 4);
+  hipLaunchKernelGGL(field_solve_kernel, dim3(ln.nenv), dim3(SBLOCK), h->solve_lds, ln.stream,
                      o.slab ? o.slab : h->part, o.ext,
                      o.ke_part, o.n, o.Ef, o.E, o.phi, o.KE, o.PE, o.PEr, a);
-  prof_end(h);
+  prof_end(h, ln.stream);
 }
 
 int refresh_fields(pic_handle* h) {
-  launch_sweep(h, ST_REFRESH, h->x, h->v, 0, 0, 0);
+  Lane ln = whole(h);
+  launch_sweep(h, ln, ST_REFRESH, h->x, h->v, 0, 0, 0);
   SolveOut o;
   o.ke_part = h->ke_part; o.n = h->n; o.Ef = h->Ef; o.E = h->E_mesh; o.phi = h->phi;
   o.KE = h->KE; o.PE = h->PE; o.PEr = h->PEr;
-  launch_solve(h, o);
+  launch_solve(h, ln, o);
   HIPCHK(h, hipGetLastError());
   h->q1_ready = true;   // ST_REFRESH also deposited the next step's q1 into part2
   return PIC_OK;
@@ -831,6 +982,32 @@ int pic_create(const pic_config* cfg, pic_handle** out) {
     CREATE_CHK(hipFuncSetAttribute((const void*)field_solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)h->solve_lds));
   CREATE_CHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+  {
+    // group size: particles (x and v) of a group <= PICSTEP_GROUP_MB; 0 disables grouping
+    const char* gm = getenv("PICSTEP_GROUP_MB");
+    const char* ns = getenv("PICSTEP_STREAMS");
+    const char* sm = getenv("PICSTEP_STEP_MAJOR");
+    const double group_mb = gm ? atof(gm) : 0.0;
+    const int nstreams = ns ? atoi(ns) : 2;
+    h->group_major = !(sm && atoi(sm) != 0);
+    const double env_mb = 2.0 * (double)h->ld * (double)h->esz / (1024.0 * 1024.0);
+    if (group_mb > 0 && nstreams >= 1) {
+      int G = (int)(group_mb / env_mb);
+      if (G < 1) G = 1;
+      if (G < cfg->num_envs) {
+        h->group_envs = G;
+        CREATE_CHK(hipEventCreateWithFlags(&h->fork_ev, hipEventDisableTiming));
+        for (int w = 0; w < nstreams; ++w) {
+          hipStream_t st;
+          hipEvent_t ev;
+          CREATE_CHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+          h->wstreams.push_back(st);
+          CREATE_CHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+          h->join_ev.push_back(ev);
+        }
+      }
+    }
+  }
   const size_t pbytes = (size_t)cfg->num_envs * h->ld * h->esz;
   const size_t gbytes = (size_t)cfg->num_envs * cfg->Ng * sizeof(double);
   CREATE_CHK(hipMalloc(&h->x, pbytes));
@@ -851,8 +1028,8 @@ int pic_create(const pic_config* cfg, pic_handle** out) {
     CREATE_CHK(hipMalloc((void**)s, (size_t)cfg->num_envs * sizeof(double)));
     CREATE_CHK(hipMemsetAsync(*s, 0, (size_t)cfg->num_envs * sizeof(double), h->stream));
   }
-  CREATE_CHK(hipMalloc((void**)&h->bad, sizeof(unsigned long long)));
-  CREATE_CHK(hipMemsetAsync(h->bad, 0, sizeof(unsigned long long), h->stream));
+  CREATE_CHK(hipMalloc((void**)&h->bad, 4 * sizeof(unsigned long long)));   // [0] bad positions, [1..3] diagnostics
+  CREATE_CHK(hipMemsetAsync(h->bad, 0, 4 * sizeof(unsigned long long), h->stream));
   CREATE_CHK(hipStreamSynchronize(h->stream));
 #undef CREATE_CHK
   *out = h;
@@ -869,6 +1046,9 @@ int pic_destroy(pic_handle* h) {
                   h->aux_n, h->aux_E, h->aux_pe, h->KE, h->PE, h->PEr, h->bad};
   for (void* b : bufs)
     if (b) hipFree(b);
+  for (hipStream_t st : h->wstreams) hipStreamDestroy(st);
+  for (hipEvent_t ev : h->join_ev) hipEventDestroy(ev);
+  if (h->fork_ev) hipEventDestroy(h->fork_ev);
   if (h->stream) hipStreamDestroy(h->stream);
   delete h;
   return PIC_OK;
@@ -923,30 +1103,68 @@ int pic_step(pic_handle* h, const double* E_ext, int mem_kind, int nsteps) {
       ext = E_ext;
     }
   }
+  // One environment step on a lane (7 launches): solve(q1 slab) B solve C solve D solve(final).
   const double* c = h->cs;
   const double* d = h->ds;
-  for (int s = 0; s < nsteps; ++s) {
+  const bool q1_ready = h->q1_ready;
+  auto one_step = [&](Lane& ln, bool have_q1) {
     SolveOut f;           // force evaluation: only the gather field is needed
     f.ext = ext; f.Ef = h->Ef;
-    if (h->q1_ready) {    // the previous sweep D / reset already deposited q1 = x + (c1 v) dt
+    if (have_q1) {        // the previous sweep D / reset already deposited q1 = x + (c1 v) dt
       SolveOut f1 = f;
       f1.slab = h->part2;
-      launch_solve(h, f1);
+      launch_solve(h, ln, f1);
     } else {
-      launch_sweep(h, ST_A, h->x, h->v, 0.0, c[0], 0.0);
-      launch_solve(h, f);
+      launch_sweep(h, ln, ST_A, h->x, h->v, 0.0, c[0], 0.0);
+      launch_solve(h, ln, f);
     }
-    launch_sweep(h, ST_B, h->x, h->v, c[0], c[1], d[1]);
-    launch_solve(h, f);
-    launch_sweep(h, ST_C, h->x, h->v, 0.0, c[2], d[2]);
-    launch_solve(h, f);
-    launch_sweep(h, ST_D, h->x, h->v, 0.0, c[3], d[3]);
+    launch_sweep(h, ln, ST_B, h->x, h->v, c[0], c[1], d[1]);
+    launch_solve(h, ln, f);
+    launch_sweep(h, ln, ST_C, h->x, h->v, 0.0, c[2], d[2]);
+    launch_solve(h, ln, f);
+    launch_sweep(h, ln, ST_D, h->x, h->v, 0.0, c[3], d[3]);
     SolveOut o;           // post-step refresh: no external field (pic.py:114-117)
     o.ke_part = h->ke_part; o.n = h->n; o.E = h->E_mesh; o.phi = h->phi;
     o.KE = h->KE; o.PE = h->PE; o.PEr = h->PEr;
-    launch_solve(h, o);
-    h->q1_ready = true;
+    launch_solve(h, ln, o);
+  };
+
+  const int E = h->cfg.num_envs;
+  const int G = h->group_envs;
+  if (G <= 0 || G >= E || h->wstreams.empty() || nsteps == 0) {
+    Lane ln = whole(h);
+    ln.parity = h->sweep_parity;
+    for (int s = 0; s < nsteps; ++s) one_step(ln, s > 0 || q1_ready);
+    h->sweep_parity = ln.parity;
+  } else {
+    // Environments are independent: walk them in cache-sized groups, neighbouring groups on different
+    // streams so that one group's field solves and kernel tails hide under the other's sweeps.
+    const int S = (int)h->wstreams.size();
+    const int ngroups = (E + G - 1) / G;
+    HIPCHK(h, hipEventRecord(h->fork_ev, h->stream));
+    for (int w = 0; w < S; ++w) HIPCHK(h, hipStreamWaitEvent(h->wstreams[w], h->fork_ev, 0));
+    int parity = h->sweep_parity;
+    if (h->group_major) {
+      for (int g = 0; g < ngroups; ++g) {
+        Lane ln{h->wstreams[g % S], g * G, (g + 1) * G <= E ? G : E - g * G, h->sweep_parity};
+        for (int s = 0; s < nsteps; ++s) one_step(ln, s > 0 || q1_ready);
+        parity = ln.parity;
+      }
+    } else {
+      for (int s = 0; s < nsteps; ++s)
+        for (int g = 0; g < ngroups; ++g) {
+          Lane ln{h->wstreams[g % S], g * G, (g + 1) * G <= E ? G : E - g * G, (h->sweep_parity + 3 * s) & 1};
+          one_step(ln, s > 0 || q1_ready);
+          parity = ln.parity;
+        }
+    }
+    h->sweep_parity = parity;
+    for (int w = 0; w < S; ++w) {
+      HIPCHK(h, hipEventRecord(h->join_ev[w], h->wstreams[w]));
+      HIPCHK(h, hipStreamWaitEvent(h->stream, h->join_ev[w], 0));
+    }
   }
+  if (nsteps > 0) h->q1_ready = true;
   HIPCHK(h, hipGetLastError());
   return PIC_OK;
 }
@@ -1079,10 +1297,11 @@ int pic_eval_field(pic_handle* h, const void* x, int mem_kind, const double* E_e
     HIPCHK(h, hipMemcpyAsync(h->ext, E_ext, gbytes, hipMemcpyHostToDevice, h->stream));
     ext = h->ext;
   }
-  launch_sweep(h, ST_PROBE, h->scratch, h->scratch, 0, 0, 0);
+  Lane ln = whole(h);
+  launch_sweep(h, ln, ST_PROBE, h->scratch, h->scratch, 0, 0, 0);
   SolveOut o;
   o.ext = ext; o.n = h->aux_n; o.E = h->aux_E; o.PEr = h->aux_pe;
-  launch_solve(h, o);
+  launch_solve(h, ln, o);
   HIPCHK(h, hipGetLastError());
   if (n) HIPCHK(h, hipMemcpyAsync(n, h->aux_n, gbytes, hipMemcpyDeviceToHost, h->stream));
   if (E_mesh) HIPCHK(h, hipMemcpyAsync(E_mesh, h->aux_E, gbytes, hipMemcpyDeviceToHost, h->stream));
@@ -1096,7 +1315,8 @@ int pic_stream_probe(pic_handle* h, int repeats, double* gbytes_per_s) {
   if (!h || !gbytes_per_s || repeats < 1) return fail(h, PIC_EINVAL, "pic_stream_probe: bad argument");
   HIPCHK(h, hipSetDevice(h->cfg.device_id));
   size_t pbytes = (size_t)h->cfg.num_envs * h->ld * h->esz;
-  if (const char* mb = getenv("PICSTEP_PROBE_MB")) pbytes = (size_t)atoll(mb) << 20;   // experiment knob
+  if (const char* mb = getenv("PICSTEP_PROBE_MB")) pbytes = (size_t)atoll(mb) << 20;   // experiment knobs
+  const int work = getenv("PICSTEP_PROBE_WORK") ? atoi(getenv("PICSTEP_PROBE_WORK")) : 0;
   void *a = nullptr, *b = nullptr;
   HIPCHK(h, hipMalloc(&a, pbytes));
   if (hipMalloc(&b, pbytes) != hipSuccess) { hipFree(a); return fail(h, PIC_ENOMEM, "pic_stream_probe: hipMalloc"); }
@@ -1109,10 +1329,10 @@ int pic_stream_probe(pic_handle* h, int repeats, double* gbytes_per_s) {
   hipEvent_t e0, e1;
   hipEventCreate(&e0);
   hipEventCreate(&e1);
-  hipLaunchKernelGGL(stream_probe_kernel, dim3((unsigned)nb), dim3(BLOCK), 0, h->stream, (double2*)a, (double2*)b, n2, chunk2, 1.0, 1);
+  hipLaunchKernelGGL(stream_probe_kernel, dim3((unsigned)nb), dim3(BLOCK), 0, h->stream, (double2*)a, (double2*)b, n2, chunk2, 1.0, 1, work);
   hipEventRecord(e0, h->stream);
   for (int r = 0; r < repeats; ++r)
-    hipLaunchKernelGGL(stream_probe_kernel, dim3((unsigned)nb), dim3(BLOCK), 0, h->stream, (double2*)a, (double2*)b, n2, chunk2, 1.0, r & 1);
+    hipLaunchKernelGGL(stream_probe_kernel, dim3((unsigned)nb), dim3(BLOCK), 0, h->stream, (double2*)a, (double2*)b, n2, chunk2, 1.0, r & 1, work);
   hipEventRecord(e1, h->stream);
   hipError_t e = hipEventSynchronize(e1);
   float ms = 0.f;
@@ -1155,10 +1375,14 @@ int pic_profile_read(pic_handle* h, double* ms_sum, int64_t* launches) {
 int pic_bad_count(pic_handle* h, int64_t* count) {
   if (!h || !count) return PIC_EINVAL;
   HIPCHK(h, hipSetDevice(h->cfg.device_id));
-  unsigned long long c = 0;
-  HIPCHK(h, hipMemcpyAsync(&c, h->bad, sizeof(c), hipMemcpyDeviceToHost, h->stream));
+  unsigned long long c[4] = {0, 0, 0, 0};
+  HIPCHK(h, hipMemcpyAsync(c, h->bad, sizeof(c), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
-  *count = (int64_t)c;
+  *count = (int64_t)c[0];
+#ifdef PIC_EXP_STAMP
+  if (c[3]) fprintf(stderr, "[stamp] sweep C wave0/block: iterations=%llu  mem-wait %.3f us/iter  push+store-issue %.3f us/iter\n",
+                    c[3], 0.01 * (double)c[1] / (double)c[3], 0.01 * (double)c[2] / (double)c[3]);
+#endif
   return PIC_OK;
 }
 

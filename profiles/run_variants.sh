@@ -7,5 +7,5 @@ for E in $2; do for V in $1; do
 import sys, json, os
 d = json.loads(sys.stdin.readline()); k = d['kernels']
 g = lambda n: k[n]['avg_ms'] if n in k else float('nan')
-print('%-12s E=%3d ms/step=%.4f ps/s=%.3e frac=%.3f A=%.4f B=%.4f C=%.4f D=%.4f solve=%.4f copy=%.0f' % (os.environ['V'], d['config']['envs_per_gpu'], d['ms_per_step'], d['value'], d['hbm_frac_of_step'], g('sweep_A'), g('sweep_B'), g('sweep_C'), g('sweep_D'), g('field_solve'), d['roofline']['measured_stream_copy_GBs']))"
+print('%-12s E=%3d ms/step=%.4f ps/s=%.3e frac=%.3f A=%.4f B=%.4f C=%.4f D=%.4f solve=%.4f copy=%.0f' % (os.environ['V'], d['config']['envs_per_gpu'], d['ms_per_step'], d['value'], d['hbm_frac_of_step'], g('sweep_A'), g('sweep_B'), g('sweep_C'), g('sweep_D'), g('field_solve'), d['roofline']['measured_inplace_copy_GBs']))"
 done; done
