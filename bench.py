@@ -95,16 +95,25 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the PIC step has no CPU path")
-    torch.cuda.set_device(local_rank)
+    # BENCH_BACKEND=gloo + BENCH_SAME_DEVICE=1: rehearsal of the N>1 path on a one-GPU box (every rank
+    # on cuda:0, collectives over gloo on host copies).  The driver's runs use the defaults: RCCL, one GPU per rank.
+    backend = os.environ.get("BENCH_BACKEND", "nccl")
+    dev_index = 0 if os.environ.get("BENCH_SAME_DEVICE") == "1" else local_rank
+    torch.cuda.set_device(dev_index)
+    cdev = f"cuda:{dev_index}" if backend == "nccl" else "cpu"      # where collective buffers live
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{dev_index}"))
+        else:
+            dist.init_process_group(backend)
 
     N, Ng, E, L = args.particles, args.mesh, args.envs, 50.0
     tdtype = torch.float64 if args.dtype == "float64" else torch.float32
-    env = BatchedPIC(E, N, Ng, L=L, dt=0.1, device=local_rank, dtype=args.dtype, accum_dtype=args.accum,
+    env = BatchedPIC(E, N, Ng, L=L, dt=0.1, device=dev_index, dtype=args.dtype, accum_dtype=args.accum,
                      blocks_per_env=args.blocks_per_env)
+    local_rank = dev_index
     x0, v0 = synth_bump_on_tail_device(torch, E, N, L, tdtype, f"cuda:{local_rank}", seed=1234 + rank)
     torch.cuda.synchronize()
     env.reset_device(x0.data_ptr(), v0.data_ptr())
@@ -123,7 +132,7 @@ def main():
     t0 = time.perf_counter()
     env.step(None, nsteps=args.steps)
     env.sync()
-    returns = torch.as_tensor(env.rewards(), device=f"cuda:{local_rank}")
+    returns = torch.as_tensor(env.rewards(), device=cdev)
     if dist is not None:
         gathered = [torch.empty_like(returns) for _ in range(world)]
         dist.all_gather(gathered, returns)          # the one collective: per-environment returns
@@ -131,7 +140,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], device=f"cuda:{local_rank}", dtype=torch.float64)
+        t = torch.tensor([elapsed], device=cdev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 

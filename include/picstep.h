@@ -112,6 +112,20 @@ int pic_get_cic(pic_handle* h, int env, int64_t* indx_l, int64_t* indx_r, double
 int pic_eval_field(pic_handle* h, const void* x, int mem_kind, const double* E_ext,
                    double* n, double* E_mesh, double* half_sum_E2_dx);
 
+/* Device-side actuator, E_field (src/control/actuator.py:4-63).  pic_set_actuator uploads the host
+ * mirror's basis tables, basis_cos / basis_sin [Ng][max_mode] float64 (they carry the reference's
+ * linspace(0, L, Ng) mesh).  pic_step_actions computes E_ext = basis_cos @ a[:M] + basis_sin @ a[M:]
+ * (actuator.py:54-63) for every environment from actions [num_envs][2*max_mode] float64 (host or
+ * device) and runs nsteps x update_state with it -- no mesh-sized host->device copy per step. */
+int pic_set_actuator(pic_handle* h, int max_mode, const double* basis_cos, const double* basis_sin);
+int pic_step_actions(pic_handle* h, const double* actions, int mem_kind, int nsteps);
+
+/* Rows 1..max_mode of compute_E_k_spectrum (src/interpret/spectrum.py:16) for the current E_mesh:
+ * Ek[m] = fft(E_mesh)[m] / Ng * 2, re / im [num_envs][max_mode] float64 (host or device, any may be
+ * NULL).  The feedback / behaviour-cloning action of run_feedback.py:133-135 and
+ * src/control/rl/ddpg.py:369-371 is (-re, +im). */
+int pic_get_modes(pic_handle* h, int max_mode, double* re, double* im, int mem_kind);
+
 /* Per-kernel timing with HIP events on the handle's stream (bench.py's roofline leg).
  * kinds: 0..3 = sweeps A..D, 4 = field solve. ms_sum / launches are arrays of 8. */
 int pic_profile(pic_handle* h, int enable);

@@ -51,6 +51,9 @@ SIGNATURES = {
     "pic_eval_field": [_vp, _vp, C.c_int, _vp, _vp, _vp, _vp],
     "pic_profile": [_vp, C.c_int],
     "pic_profile_read": [_vp, _dp, _i64p],
+    "pic_set_actuator": [_vp, C.c_int, _vp, _vp],
+    "pic_step_actions": [_vp, _vp, C.c_int, C.c_int],
+    "pic_get_modes": [_vp, C.c_int, _vp, _vp, C.c_int],
     "pic_stream_probe": [_vp, C.c_int, _dp],
     "pic_sync": [_vp],
     "pic_bad_count": [_vp, _i64p],
@@ -236,6 +239,27 @@ class Handle:
         cnt = (C.c_int64 * 8)()
         self._chk(self.lib.pic_profile_read(self._h, ms, cnt))
         return {KIND_NAMES[i]: (ms[i], cnt[i]) for i in range(6) if cnt[i]}
+
+    def set_actuator(self, basis_cos, basis_sin):
+        bc = np.ascontiguousarray(basis_cos, dtype=np.float64)
+        bs = np.ascontiguousarray(basis_sin, dtype=np.float64)
+        if bc.shape != bs.shape or bc.shape[0] != self.Ng:
+            raise ValueError("basis tables must be [Ng, max_mode]")
+        self.max_mode = int(bc.shape[1])
+        self._chk(self.lib.pic_set_actuator(self._h, self.max_mode, _ptr(bc), _ptr(bs)))
+
+    def step_actions(self, actions, nsteps=1):
+        a = np.ascontiguousarray(np.asarray(actions, dtype=np.float64).reshape(self.num_envs, 2 * self.max_mode))
+        self._chk(self.lib.pic_step_actions(self._h, _ptr(a), PIC_HOST, int(nsteps)))
+
+    def step_actions_device(self, actions_ptr, nsteps=1):
+        self._chk(self.lib.pic_step_actions(self._h, _ptr(int(actions_ptr)), PIC_DEVICE, int(nsteps)))
+
+    def modes(self, max_mode):
+        re = np.empty((self.num_envs, int(max_mode)))
+        im = np.empty_like(re)
+        self._chk(self.lib.pic_get_modes(self._h, int(max_mode), _ptr(re), _ptr(im), PIC_HOST))
+        return re + 1j * im
 
     def stream_probe(self, repeats=10):
         g = C.c_double()

@@ -656,6 +656,49 @@ __global__ __launch_bounds__(BLOCK) void cic_query_kernel(const T* __restrict__ 
   }
 }
 
+// E_field.compute_E (src/control/actuator.py:54-63) for every environment:
+// E_ext[e][j] = sum_m basis_cos[j][m] a[e][m] + sum_m basis_sin[j][m] a[e][M+m].  The basis tables come from the
+// host mirror (they carry the reference's linspace(0, L, Ng) mesh, actuator.py:13).
+__global__ __launch_bounds__(BLOCK) void actuator_kernel(const double* __restrict__ bc, const double* __restrict__ bs,
+                                                         const double* __restrict__ act, double* __restrict__ ext,
+                                                         int Ng, int M) {
+  const int env = blockIdx.y;
+  const int j = blockIdx.x * BLOCK + threadIdx.x;
+  if (j >= Ng) return;
+  const double* a = act + (size_t)env * 2 * M;
+  double c = 0.0, s = 0.0;
+  for (int m = 0; m < M; ++m) c += bc[(size_t)j * M + m] * a[m];
+  for (int m = 0; m < M; ++m) s += bs[(size_t)j * M + m] * a[M + m];
+  ext[(size_t)env * Ng + j] = c + s;
+}
+
+// compute_E_k_spectrum rows 1..M (src/interpret/spectrum.py:16): Ek[m] = fft(E_mesh)[m] / Ng * 2.
+__global__ __launch_bounds__(BLOCK) void modes_kernel(const double* __restrict__ E_mesh, double* __restrict__ re,
+                                                      double* __restrict__ im, int Ng, int M) {
+  __shared__ double wr[WAVES], wi[WAVES];
+  const int env = blockIdx.y, m = blockIdx.x + 1;
+  double sr = 0.0, si = 0.0;
+  for (int j = threadIdx.x; j < Ng; j += BLOCK) {
+    // angle = 2 pi m j / Ng, reduced exactly in integers before the trig call
+    const long long r = ((long long)m * j) % Ng;
+    double sn, cs;
+    sincospi(2.0 * (double)r / (double)Ng, &sn, &cs);
+    const double e = E_mesh[(size_t)env * Ng + j];
+    sr += e * cs;
+    si -= e * sn;
+  }
+  sr = wave_sum(sr);
+  si = wave_sum(si);
+  if ((threadIdx.x & 63) == 0) { wr[threadIdx.x >> 6] = sr; wi[threadIdx.x >> 6] = si; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double a = 0.0, b = 0.0;
+    for (int w = 0; w < WAVES; ++w) { a += wr[w]; b += wi[w]; }
+    re[(size_t)env * M + (m - 1)] = a / Ng * 2.0;
+    im[(size_t)env * M + (m - 1)] = b / Ng * 2.0;
+  }
+}
+
 // Streaming ceiling of this box for the sweeps' access shape: read two arrays, write two arrays, 16 B
 // per lane, same grid -- what a sweep would take if it did no arithmetic at all.
 __global__ __launch_bounds__(BLOCK) void stream_probe_kernel(double2* __restrict__ a, double2* __restrict__ b,
@@ -713,7 +756,11 @@ struct pic_handle {
   double* n = nullptr;
   double* E_mesh = nullptr;
   double* phi = nullptr;
-  double* ext = nullptr;          // device copy of a host E_ext
+  double* ext = nullptr;          // device copy of a host E_ext / output of the device actuator
+  double* basis = nullptr;        // [2][Ng][M] actuator tables (cos, sin)
+  double* act = nullptr;          // [env][2M] actions
+  double* modes = nullptr;        // [2][env][M] Fourier modes (re, im)
+  int act_modes = 0;
   double* aux_n = nullptr;        // eval_field outputs
   double* aux_E = nullptr;
   double* aux_pe = nullptr;
@@ -1042,6 +1089,9 @@ int pic_destroy(pic_handle* h) {
   if (h->stream) hipStreamSynchronize(h->stream);
   prof_drain(h);
   for (hipEvent_t e : h->ev) hipEventDestroy(e);
+  if (h->basis) hipFree(h->basis);
+  if (h->act) hipFree(h->act);
+  if (h->modes) hipFree(h->modes);
   void* bufs[] = {h->x, h->v, h->scratch, h->part, h->part2, h->ke_part, h->Ef, h->n, h->E_mesh, h->phi, h->ext,
                   h->aux_n, h->aux_E, h->aux_pe, h->KE, h->PE, h->PEr, h->bad};
   for (void* b : bufs)
@@ -1307,6 +1357,60 @@ int pic_eval_field(pic_handle* h, const void* x, int mem_kind, const double* E_e
   if (E_mesh) HIPCHK(h, hipMemcpyAsync(E_mesh, h->aux_E, gbytes, hipMemcpyDeviceToHost, h->stream));
   if (half_sum_E2_dx)
     HIPCHK(h, hipMemcpyAsync(half_sum_E2_dx, h->aux_pe, (size_t)h->cfg.num_envs * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return PIC_OK;
+}
+
+int pic_set_actuator(pic_handle* h, int max_mode, const double* basis_cos, const double* basis_sin) {
+  if (!h || !basis_cos || !basis_sin || max_mode < 1 || max_mode > 64)
+    return fail(h, PIC_EINVAL, "pic_set_actuator: need 1 <= max_mode <= 64 and both basis tables");
+  HIPCHK(h, hipSetDevice(h->cfg.device_id));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  if (h->basis) { hipFree(h->basis); h->basis = nullptr; }
+  if (h->act) { hipFree(h->act); h->act = nullptr; }
+  const size_t tb = (size_t)h->cfg.Ng * max_mode * sizeof(double);
+  HIPCHK(h, hipMalloc((void**)&h->basis, 2 * tb));
+  HIPCHK(h, hipMalloc((void**)&h->act, (size_t)h->cfg.num_envs * 2 * max_mode * sizeof(double)));
+  HIPCHK(h, hipMemcpyAsync(h->basis, basis_cos, tb, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipMemcpyAsync((char*)h->basis + tb, basis_sin, tb, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  h->act_modes = max_mode;
+  return PIC_OK;
+}
+
+int pic_step_actions(pic_handle* h, const double* actions, int mem_kind, int nsteps) {
+  if (!h || !actions) return fail(h, PIC_EINVAL, "pic_step_actions: null argument");
+  if (!h->act_modes) return fail(h, PIC_ESTATE, "pic_step_actions: call pic_set_actuator first");
+  HIPCHK(h, hipSetDevice(h->cfg.device_id));
+  const int M = h->act_modes, Ng = h->cfg.Ng;
+  const double* a = actions;
+  if (mem_kind == PIC_HOST) {
+    HIPCHK(h, hipMemcpyAsync(h->act, actions, (size_t)h->cfg.num_envs * 2 * M * sizeof(double), hipMemcpyHostToDevice,
+                             h->stream));
+    a = h->act;
+  }
+  hipLaunchKernelGGL(actuator_kernel, dim3((Ng + BLOCK - 1) / BLOCK, h->cfg.num_envs), dim3(BLOCK), 0, h->stream,
+                     h->basis, h->basis + (size_t)Ng * M, a, h->ext, Ng, M);
+  HIPCHK(h, hipGetLastError());
+  return pic_step(h, h->ext, PIC_DEVICE, nsteps);
+}
+
+int pic_get_modes(pic_handle* h, int max_mode, double* re, double* im, int mem_kind) {
+  if (!h || max_mode < 1 || max_mode >= h->cfg.Ng) return fail(h, PIC_EINVAL, "pic_get_modes: bad max_mode");
+  if (!h->has_state) return fail(h, PIC_ESTATE, "pic_get_modes: call pic_reset first");
+  HIPCHK(h, hipSetDevice(h->cfg.device_id));
+  const size_t nb = (size_t)h->cfg.num_envs * max_mode * sizeof(double);
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  if (h->modes) { hipFree(h->modes); h->modes = nullptr; }
+  HIPCHK(h, hipMalloc((void**)&h->modes, 2 * nb));
+  double* dre = h->modes;
+  double* dim_ = h->modes + (size_t)h->cfg.num_envs * max_mode;
+  hipLaunchKernelGGL(modes_kernel, dim3(max_mode, h->cfg.num_envs), dim3(BLOCK), 0, h->stream, h->E_mesh, dre, dim_,
+                     h->cfg.Ng, max_mode);
+  HIPCHK(h, hipGetLastError());
+  const hipMemcpyKind k = mem_kind == PIC_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
+  if (re) HIPCHK(h, hipMemcpyAsync(re, dre, nb, k, h->stream));
+  if (im) HIPCHK(h, hipMemcpyAsync(im, dim_, nb, k, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   return PIC_OK;
 }

@@ -78,6 +78,30 @@ class BatchedPIC:
     def eval_field(self, x, E_ext=None):
         return self._h.eval_field(x, E_ext)
 
+    # -- control loop on the device ---------------------------------------
+    def set_actuator(self, actuator):
+        """Upload an `E_field`'s basis tables (its linspace mesh included) for `step_actions`."""
+        self._h.set_actuator(actuator.basis_cos, actuator.basis_sin)
+        self.max_mode = actuator.max_mode
+
+    def step_actions(self, actions, nsteps: int = 1):
+        """actions [num_envs, 2*max_mode] (cos coefficients, then sin): E_ext is built on the device
+        (actuator.py:54-63) and held for `nsteps` steps."""
+        self._h.step_actions(actions, nsteps)
+
+    def step_actions_device(self, actions_ptr, nsteps: int = 1):
+        self._h.step_actions_device(actions_ptr, nsteps)
+
+    def modes(self, max_mode: int):
+        """Complex [num_envs, max_mode]: rows 1..max_mode of compute_E_k_spectrum for the current E_mesh."""
+        return self._h.modes(max_mode)
+
+    def feedback_actions(self, max_mode: int):
+        """The linear-feedback / behaviour-cloning action of run_feedback.py:133-135 and ddpg.py:369-371:
+        cos coefficients -Re(E_k), sin coefficients +Im(E_k), k = 1..max_mode."""
+        ek = self.modes(max_mode)
+        return np.concatenate([-ek.real, ek.imag], axis=1)
+
     def stream_probe(self, repeats=10):
         """GB/s of a read-2-arrays / write-2-arrays copy with the sweeps' grid on this device."""
         return self._h.stream_probe(repeats)

@@ -379,6 +379,81 @@ def test_torch_zero_copy_views(oc, po):
     assert np.array_equal(obs.cpu().numpy(), env.get_state())
 
 
+def test_device_actuator_and_feedback_modes(oc, po):
+    """actions -> E_ext on the device (golden g8 pins the host tables it uses) and the
+    first Fourier modes of E_mesh (golden g9 pins the spectrum definition)."""
+    E_, N, Ng, L, M = 3, 25000, 250, 50.0, 5
+    xs, vs = zip(*[po.synthetic_two_stream(N, L, seed=70 + e) for e in range(E_)])
+    x0, v0 = np.stack(xs), np.stack(vs)
+    act = oc.E_field(L, Ng, M)
+    a = oc.BatchedPIC(E_, N, Ng, L=L, dt=0.05)
+    b = oc.BatchedPIC(E_, N, Ng, L=L, dt=0.05)
+    a.set_actuator(act)
+    for env in (a, b):
+        env.reset(x0, v0)
+    rng = np.random.default_rng(3)
+    for k in range(4):
+        actions = rng.uniform(-1.25, 1.25, (E_, 2 * M))
+        a.step_actions(actions, nsteps=2)                        # E_ext built on the device
+        b.step(act.compute_E_batched(actions), nsteps=2)         # E_ext built by the host mirror
+    (xa, va), (xb, vb) = a.particles(), b.particles()
+    assert circ_err(xa, xb, L) / L < 1e-13 and rel_err(va, vb) < 1e-12
+    # modes of the current field vs numpy's FFT, definition of spectrum.py:16
+    _, Em, _ = a.fields()
+    ref = (np.fft.fft(Em, axis=1) / Ng * 2.0)[:, 1:M + 1]
+    ek = a.modes(M)
+    assert rel_err(ek, ref) < 1e-12
+    fb = a.feedback_actions(M)
+    assert fb.shape == (E_, 2 * M) and np.allclose(fb[:, :M], -ref.real, atol=1e-14) and np.allclose(fb[:, M:], ref.imag, atol=1e-14)
+    # the same numbers through the reference-shaped host function on a state snapshot
+    st = a.get_state()[0].reshape(-1, 1)
+    ks, Ek = oc.compute_E_k_spectrum(1.0, L, L / Ng, Ng, st, False)
+    assert rel_err(Ek[1:M + 1, 0], ek[0]) < 1e-10
+
+
+def test_edge_sizes(oc, po):
+    """Ragged and extreme shapes: fewer particles than one tile, one particle, the largest mesh,
+    a mesh over the LDS limit, zero steps."""
+    L = 50.0
+    for N, Ng in ((1, 8), (7, 16), (511, 64), (513, 64), (4097, 2700)):
+        rng = np.random.default_rng(N)
+        x0, v0 = rng.uniform(0, L, N), rng.normal(0, 1, N)
+        env = oc.BatchedPIC(2, N, Ng, L=L, dt=0.05)
+        env.reset(np.stack([x0, x0]), np.stack([v0, -v0]))
+        env.step(None, 0)
+        env.step(None, 3)
+        ref = po.OraclePIC(x0, v0, Ng, L=L, dt=0.05, perturb=False, faithful=False)
+        assert ref.dt == env.dt
+        if np.isfinite(ref.E_mesh).all():       # the reference's own solve blows up for some (L, Ng) pairs
+            for _ in range(3):
+                ref.update_state(None)
+            x, v = env.particles()
+            assert circ_err(x[0], ref.x, L) / L < 1e-12 and rel_err(v[0], ref.v) < 1e-11, (N, Ng)
+            assert rel_err(env.fields()[1][0], ref.E_mesh) < 1e-9, (N, Ng)
+        n = env.fields()[0]
+        assert np.allclose(n.sum(axis=1) * (L / Ng), L, rtol=1e-12) and env.bad_count() == 0
+        env.close()
+    with pytest.raises(oc._abi.PicError, match="Ng too large"):
+        oc.BatchedPIC(1, 1000, 4096, L=L, dt=0.05)
+
+
+def test_many_small_envs(oc, po):
+    """1024 environments in one handle (BASELINE config 5's env count at a small N)."""
+    E_, N, Ng, L = 1024, 2000, 64, 50.0
+    rng = np.random.default_rng(0)
+    x0, v0 = rng.uniform(0, L, (E_, N)), rng.normal(0, 1, (E_, N))
+    env = oc.BatchedPIC(E_, N, Ng, L=L, dt=0.05)
+    env.reset(x0, v0)
+    env.step(None, 5)
+    ke, pe, per = env.energies()
+    for e in (0, 511, 1023):
+        ref = po.OraclePIC(x0[e], v0[e], Ng, L=L, dt=0.05, perturb=False, faithful=False)
+        for _ in range(5):
+            ref.update_state(None)
+        assert abs(ke[e] / ref.kinetic_energy() - 1) < 1e-12 and abs(pe[e] / ref.get_electric_energy() - 1) < 1e-8
+    assert env.bad_count() == 0
+
+
 def test_errors_cross_the_abi_as_codes(oc):
     h = oc._abi.Handle(1000, 64, 1, 50.0, 1.0, 0.1)
     with pytest.raises(oc._abi.PicError, match="pic_reset first"):
