@@ -117,7 +117,9 @@ class Handle:
                  accum_dtype=None, interpol="CIC", device_id=0, blocks_per_env=0):
         self.lib = load()
         pd = {"float64": PIC_F64, "float32": PIC_F32}[str(np.dtype(particle_dtype))]
-        ad = pd if accum_dtype is None else {"float64": PIC_F64, "float32": PIC_F32}[str(np.dtype(accum_dtype))]
+        # LDS mesh accumulator: float64 unless asked otherwise, also for float32 particles -- measured on
+        # MI355X, ds_add_f32 deposition runs ~4x slower than ds_add_f64 (profiles/experiments_r1.md)
+        ad = PIC_F64 if accum_dtype is None else {"float64": PIC_F64, "float32": PIC_F32}[str(np.dtype(accum_dtype))]
         self.cfg = PicConfig(int(N), int(Ng), int(num_envs), float(L), float(n0), float(dt), float(gamma), pd, ad,
                              {"CIC": PIC_CIC, "TSC": PIC_TSC}[interpol], int(device_id), int(blocks_per_env), 0)
         self.N, self.Ng, self.num_envs = int(N), int(Ng), int(num_envs)

@@ -767,6 +767,7 @@ struct pic_handle {
   double* KE = nullptr;
   double* PE = nullptr;
   double* PEr = nullptr;
+  double* h_scal = nullptr;       // pinned host staging for KE | PE | PE_reward
   unsigned long long* bad = nullptr;
   bool has_state = false;
   // profiling
@@ -1070,11 +1071,16 @@ int pic_create(const pic_config* cfg, pic_handle** out) {
     CREATE_CHK(hipMalloc((void**)g, gbytes));
     CREATE_CHK(hipMemsetAsync(*g, 0, gbytes, h->stream));
   }
-  double** scal[] = {&h->KE, &h->PE, &h->PEr, &h->aux_pe};
-  for (double** s : scal) {
-    CREATE_CHK(hipMalloc((void**)s, (size_t)cfg->num_envs * sizeof(double)));
-    CREATE_CHK(hipMemsetAsync(*s, 0, (size_t)cfg->num_envs * sizeof(double), h->stream));
-  }
+  // KE | PE | PE_reward live in one allocation so that a getter is a single small D2H copy into
+  // pinned memory (a Python RL loop reads them every step)
+  const size_t sbytes = (size_t)cfg->num_envs * sizeof(double);
+  CREATE_CHK(hipMalloc((void**)&h->KE, 3 * sbytes));
+  CREATE_CHK(hipMemsetAsync(h->KE, 0, 3 * sbytes, h->stream));
+  h->PE = h->KE + cfg->num_envs;
+  h->PEr = h->KE + 2 * (size_t)cfg->num_envs;
+  CREATE_CHK(hipHostMalloc((void**)&h->h_scal, 3 * sbytes, hipHostMallocDefault));
+  CREATE_CHK(hipMalloc((void**)&h->aux_pe, sbytes));
+  CREATE_CHK(hipMemsetAsync(h->aux_pe, 0, sbytes, h->stream));
   CREATE_CHK(hipMalloc((void**)&h->bad, 4 * sizeof(unsigned long long)));   // [0] bad positions, [1..3] diagnostics
   CREATE_CHK(hipMemsetAsync(h->bad, 0, 4 * sizeof(unsigned long long), h->stream));
   CREATE_CHK(hipStreamSynchronize(h->stream));
@@ -1093,9 +1099,10 @@ int pic_destroy(pic_handle* h) {
   if (h->act) hipFree(h->act);
   if (h->modes) hipFree(h->modes);
   void* bufs[] = {h->x, h->v, h->scratch, h->part, h->part2, h->ke_part, h->Ef, h->n, h->E_mesh, h->phi, h->ext,
-                  h->aux_n, h->aux_E, h->aux_pe, h->KE, h->PE, h->PEr, h->bad};
+                  h->aux_n, h->aux_E, h->aux_pe, h->KE, h->bad};
   for (void* b : bufs)
     if (b) hipFree(b);
+  if (h->h_scal) hipHostFree(h->h_scal);
   for (hipStream_t st : h->wstreams) hipStreamDestroy(st);
   for (hipEvent_t ev : h->join_ev) hipEventDestroy(ev);
   if (h->fork_ev) hipEventDestroy(h->fork_ev);
@@ -1259,11 +1266,12 @@ int pic_get_fields(pic_handle* h, double* n, double* E_mesh, double* phi) {
 int pic_get_energies(pic_handle* h, double* KE, double* PE, double* PE_reward) {
   if (!h) return PIC_EINVAL;
   HIPCHK(h, hipSetDevice(h->cfg.device_id));
-  const size_t b = (size_t)h->cfg.num_envs * sizeof(double);
-  if (KE) HIPCHK(h, hipMemcpyAsync(KE, h->KE, b, hipMemcpyDeviceToHost, h->stream));
-  if (PE) HIPCHK(h, hipMemcpyAsync(PE, h->PE, b, hipMemcpyDeviceToHost, h->stream));
-  if (PE_reward) HIPCHK(h, hipMemcpyAsync(PE_reward, h->PEr, b, hipMemcpyDeviceToHost, h->stream));
+  const size_t E = (size_t)h->cfg.num_envs, b = E * sizeof(double);
+  HIPCHK(h, hipMemcpyAsync(h->h_scal, h->KE, 3 * b, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
+  if (KE) std::memcpy(KE, h->h_scal, b);
+  if (PE) std::memcpy(PE, h->h_scal + E, b);
+  if (PE_reward) std::memcpy(PE_reward, h->h_scal + 2 * E, b);
   return PIC_OK;
 }
 

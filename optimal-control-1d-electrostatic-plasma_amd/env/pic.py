@@ -198,19 +198,26 @@ class PIC:
         x, v = self._particles()
         return np.concatenate([x.copy().reshape(-1, 1), v.copy().reshape(-1, 1)], axis=0)
 
+    def _energies(self):
+        """(KE, PE, PE_reward) of the current state: one small device read per step, then cached."""
+        if "energies" not in self._cache:
+            ke, pe, per = self._ensure_handle().energies()
+            self._cache["energies"] = (float(ke[0]), float(pe[0]), float(per[0]))
+        return self._cache["energies"]
+
     def get_energy(self):
-        ke, pe, _ = self._ensure_handle().energies()
-        return float(ke[0] + pe[0])
+        ke, pe, _ = self._energies()
+        return ke + pe
 
     def get_electric_energy(self):
-        return float(self._ensure_handle().energies()[1][0])
+        return self._energies()[1]
 
     def get_kinetic_energy(self):
-        return float(self._ensure_handle().energies()[0][0])
+        return self._energies()[0]
 
     def get_reward_electric_energy(self):
         """0.5*sum(E_mesh^2)*dx of the current state = Reward.compute_electric_energy(get_state())."""
-        return float(self._ensure_handle().energies()[2][0])
+        return self._energies()[2]
 
     def simulate(self, E_external_traj: Optional[List[np.ndarray]] = None):
         """pic.py:175-223: returns snapshot (2N, Nt+1), E (Nt+1,), PE (Nt+1,)."""
@@ -236,8 +243,8 @@ class PIC:
         evaluate it (ddpg.py:455)."""
         pe_pre = self.get_reward_electric_energy()
         self.update_state(E_external)
-        ke, pe, per = self._ensure_handle().energies()
-        info = {"KE": float(ke[0]), "PE": float(pe[0]), "PE_reward": float(per[0])}
+        ke, pe, per = self._energies()
+        info = {"KE": ke, "PE": pe, "PE_reward": per}
         return self.get_state(), max(1.0 - pe_pre, 0.0), False, info
 
     def close(self):
