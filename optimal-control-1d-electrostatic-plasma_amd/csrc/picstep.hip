@@ -292,7 +292,14 @@ __global__ __launch_bounds__(BLOCK) void sweep_kernel(T* __restrict__ x, T* __re
   const int env = a.env0 + (a.reverse ? (int)gridDim.y - 1 - (int)blockIdx.y : (int)blockIdx.y);
   const int blk = a.reverse ? (int)gridDim.x - 1 - (int)blockIdx.x : (int)blockIdx.x;
 
+#ifdef PIC_EXP_STAMPB
+  const unsigned long long sb0 = wall_clock64();
+#endif
   for (int i = tid; i < nacc; i += BLOCK) acc_all[i] = A(0);
+#ifdef PIC_EXP_STAMPB
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  const unsigned long long sbz = wall_clock64();
+#endif
   if (kGather) {
     const double* Ee = Ef + (size_t)env * Ng;
     for (int i = tid; i < stride; i += BLOCK) {
@@ -301,6 +308,10 @@ __global__ __launch_bounds__(BLOCK) void sweep_kernel(T* __restrict__ x, T* __re
       Es[i] = (T)Ee[node];
     }
   }
+#ifdef PIC_EXP_STAMPB
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  const unsigned long long sbe = wall_clock64();
+#endif
   __syncthreads();
 
   const int rep = (tid >> 6) & (a.R - 1);
@@ -318,6 +329,9 @@ __global__ __launch_bounds__(BLOCK) void sweep_kernel(T* __restrict__ x, T* __re
 
   double ke = 0.0;
   unsigned bad = 0u;
+#ifdef PIC_EXP_STAMPB
+  const unsigned long long sb1 = wall_clock64();
+#endif
   long long i = begin + (long long)tid * VEC;
 #if PIC_PIPE == 0
   // PIC_TILES tiles per lane per iteration: all their loads are issued before the first particle is
@@ -408,10 +422,18 @@ __global__ __launch_bounds__(BLOCK) void sweep_kernel(T* __restrict__ x, T* __re
     cx = PIC_LOAD(reinterpret_cast<const V*>(xe + i));
     if (kReadV) cv = PIC_LOAD(reinterpret_cast<const V*>(ve + i));
   }
+#ifdef PIC_EXP_STAMP
+  unsigned long long st_mem = 0, st_cmp = 0, st_n = 0;
+#endif
   while (have) {
     const long long in = i + step;
     const bool hn = (in + VEC <= end);
     V nx = {}, nv = {};
+#ifdef PIC_EXP_STAMP
+    __builtin_amdgcn_sched_barrier(0);
+    const unsigned long long st0 = wall_clock64();
+    __builtin_amdgcn_sched_barrier(0);
+#endif
     if (hn) {
       if (kReadV)
         asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %3, off"
@@ -431,14 +453,35 @@ __global__ __launch_bounds__(BLOCK) void sweep_kernel(T* __restrict__ x, T* __re
       PIC_STORE(cx, reinterpret_cast<V*>(xe + i));
       if (kStoreV) PIC_STORE(cv, reinterpret_cast<V*>(ve + i));
     }
+#ifdef PIC_EXP_STAMP
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const unsigned long long st1 = wall_clock64();
+    __builtin_amdgcn_sched_barrier(0);
+#endif
     if (kNumStores == 2) asm volatile("s_waitcnt vmcnt(2)" : "+v"(nx), "+v"(nv) : : "memory");
     else if (kNumStores == 1) asm volatile("s_waitcnt vmcnt(1)" : "+v"(nx), "+v"(nv) : : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" : "+v"(nx), "+v"(nv) : : "memory");
+#ifdef PIC_EXP_STAMP
+    __builtin_amdgcn_sched_barrier(0);
+    const unsigned long long st2 = wall_clock64();
+    __builtin_amdgcn_sched_barrier(0);
+    st_cmp += st1 - st0;      // issue prefetch + push + issue stores
+    st_mem += st2 - st1;      // residual wait for the prefetched tile
+    st_n += 1;
+#endif
     cx = nx;
     cv = nv;
     i = in;
     have = hn;
   }
+#ifdef PIC_EXP_STAMP
+  if (tid == 0 && (STAGE == ST_C)) {
+    atomicAdd(&bad_count[1], st_mem);
+    atomicAdd(&bad_count[2], st_cmp);
+    atomicAdd(&bad_count[3], st_n);
+  }
+#endif
 #endif
   for (long long k = i; k < end; ++k) {       // ragged tail (fewer than VEC particles left for this lane)
     T xq = xe[k];
@@ -449,7 +492,13 @@ __global__ __launch_bounds__(BLOCK) void sweep_kernel(T* __restrict__ x, T* __re
       if (kStoreV) ve[k] = pv;
     }
   }
+#ifdef PIC_EXP_STAMPB
+  const unsigned long long sb2 = wall_clock64();      // this wave's loop is done
+#endif
   __syncthreads();
+#ifdef PIC_EXP_STAMPB
+  const unsigned long long sb3 = wall_clock64();      // every wave's loop is done
+#endif
 
   const size_t rowi = ((size_t)env * a.nblk + blk) * Ng;
   flush_mesh<A, SHAPE>(acc_all, a.R, stride, Ng, part + rowi);
@@ -466,6 +515,19 @@ __global__ __launch_bounds__(BLOCK) void sweep_kernel(T* __restrict__ x, T* __re
     }
   }
   if (bad) atomicAdd(bad_count, (unsigned long long)bad);
+#ifdef PIC_EXP_STAMPB
+  if (STAGE == ST_C && (tid & 63) == 0) {
+    const unsigned long long sb4 = wall_clock64();
+    // [1] prologue+loop of this wave, [2] wait for the slowest wave of the workgroup, [3] flush; counts in [0]'s upper bits unused
+    const bool late = (unsigned)(blockIdx.y * gridDim.x + blockIdx.x) >= 2048u;   // not in the first resident set
+    if (late) {
+      atomicAdd(&bad_count[1], ((sbz - sb0) << 32) | (sbe - sbz));     // zero LDS | field tile load
+      atomicAdd(&bad_count[2], ((sb1 - sbe) << 32) | (sb2 - sb1));     // barrier | loop
+      atomicAdd(&bad_count[3], ((sb3 - sb2) << 32) | 1ull);            // straggler wait | count
+    }
+    (void)sb4;
+  }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1491,6 +1553,14 @@ int pic_bad_count(pic_handle* h, int64_t* count) {
   HIPCHK(h, hipMemcpyAsync(c, h->bad, sizeof(c), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   *count = (int64_t)c[0];
+#ifdef PIC_EXP_STAMPB
+  if (c[3]) {
+    const double nw = (double)(c[3] & 0xffffffffull);
+    fprintf(stderr, "[stampB] sweep C, late workgroups, per wave: zero-LDS %.2f us  field-tile load %.2f us  barrier %.2f us  loop %.2f us  straggler wait %.2f us  (waves=%.0f)\n",
+            0.01 * (double)(c[1] >> 32) / nw, 0.01 * (double)(c[1] & 0xffffffffull) / nw, 0.01 * (double)(c[2] >> 32) / nw,
+            0.01 * (double)(c[2] & 0xffffffffull) / nw, 0.01 * (double)(c[3] >> 32) / nw, nw);
+  }
+#endif
 #ifdef PIC_EXP_STAMP
   if (c[3]) fprintf(stderr, "[stamp] sweep C wave0/block: iterations=%llu  mem-wait %.3f us/iter  push+store-issue %.3f us/iter\n",
                     c[3], 0.01 * (double)c[1] / (double)c[3], 0.01 * (double)c[2] / (double)c[3]);
