@@ -1,50 +1,63 @@
-"""`E_field` -- the actuator of ``src/control/actuator.py:4-63``: Fourier coefficients -> external
-field on the mesh, ``E_ext = basis_cos @ a + basis_sin @ b`` with shape ``(N_mesh, 1)``.
+"""Actuator: Fourier coefficients of the control -> external electric field on the mesh.
 
-Kept on the host (an ``Ng x 2M`` product with M <= 5); it produces the ``E_external`` that
-``PIC.update_state`` hands to the device.  The mesh is ``linspace(0, L, N_mesh)`` with the end
-point INCLUDED (actuator.py:13), not ``j*dx`` -- preserved on purpose.
+Public surface of the reference's `E_field` (``src/control/actuator.py:4-63``): attributes ``L,
+N_mesh, dx, max_mode, xm, k, basis_cos, basis_sin, coeff_cos, coeff_sin`` and methods ``reinit,
+update_E, compute_E, update_params``.  The field is
+
+    E_ext(x_j) = sum_m a_m cos(k_m x_j) + b_m sin(k_m x_j),   k_m = 2 pi m / L,  m = 1..max_mode
+
+on the mesh ``x_j = linspace(0, L, N_mesh)[j]`` -- end point INCLUDED (actuator.py:13), i.e. the
+nodes are ``j L / (N_mesh - 1)``, not the PIC mesh ``j dx``.  That quirk is kept on purpose: fields
+computed here equal the reference's bit for bit (tests/golden/g8_actuator.npz).
+
+Host side, for one environment.  For batches, ``compute_E_batched`` does the same product for
+``[num_envs, 2 max_mode]`` actions, and ``BatchedPIC.set_actuator(self)`` uploads the two basis
+tables so that ``BatchedPIC.step_actions`` builds ``E_ext`` on the device.
 """
-from typing import Optional
-
 import numpy as np
 
+from .._params import ParamMixin
 
-class E_field:
+
+def fourier_basis(L, N_mesh, max_mode):
+    """(xm, k, cos table, sin table); tables are [N_mesh, max_mode] with entry cos/sin(k_m * xm_j)."""
+    xm = np.linspace(0, L, N_mesh)
+    k = np.array([2 * np.pi / L * m for m in range(1, max_mode + 1)])
+    phase = np.multiply.outer(xm, k)          # xm_j * k_m, the product the reference forms as k * xm
+    return xm, k, np.cos(phase), np.sin(phase)
+
+
+def _column(values):
+    return np.array(values, dtype=float).reshape(-1, 1)
+
+
+class E_field(ParamMixin):
     def __init__(self, L: float, N_mesh: int, max_mode: int):
-        self.L = L
-        self.N_mesh = N_mesh
+        self.L, self.N_mesh, self.max_mode = L, N_mesh, max_mode
         self.dx = L / N_mesh
-        self.max_mode = max_mode
         self.reinit()
 
-    def update_params(self, **kwargs):
-        for key, val in kwargs.items():
-            if hasattr(self, key) and val is not None:
-                setattr(self, key, val)
-
     def reinit(self):
-        self.xm = np.linspace(0, self.L, self.N_mesh)
+        """Rebuild mesh and tables from the current L / N_mesh / max_mode and zero the coefficients."""
+        self.xm, self.k, self.basis_cos, self.basis_sin = fourier_basis(self.L, self.N_mesh, self.max_mode)
         self.coeff_cos = np.zeros((self.max_mode, 1))
         self.coeff_sin = np.zeros((self.max_mode, 1))
-        self.k = np.array([2 * np.pi / self.L * m for m in range(1, self.max_mode + 1)])
-        phase = self.xm.reshape(-1, 1) * self.k.reshape(1, -1)     # (Ng, M): k * xm per column
-        self.basis_cos = np.cos(phase)
-        self.basis_sin = np.sin(phase)
 
-    def update_E(self, coeff_cos: Optional[np.ndarray] = None, coeff_sin: Optional[np.ndarray] = None):
+    def update_E(self, coeff_cos=None, coeff_sin=None):
+        """Store new coefficients (copies, as columns); None leaves that half unchanged."""
         if coeff_cos is not None:
-            self.coeff_cos = np.array(coeff_cos, dtype=float).reshape(-1, 1)
+            self.coeff_cos = _column(coeff_cos)
         if coeff_sin is not None:
-            self.coeff_sin = np.array(coeff_sin, dtype=float).reshape(-1, 1)
+            self.coeff_sin = _column(coeff_sin)
 
-    def compute_E(self, coeff_cos: Optional[np.ndarray] = None, coeff_sin: Optional[np.ndarray] = None):
-        cc = self.coeff_cos if coeff_cos is None else np.asarray(coeff_cos, dtype=float)
-        cs = self.coeff_sin if coeff_sin is None else np.asarray(coeff_sin, dtype=float)
-        return self.basis_cos @ cc.reshape(-1, 1) + self.basis_sin @ cs.reshape(-1, 1)
+    def compute_E(self, coeff_cos=None, coeff_sin=None):
+        """External field as an ``(N_mesh, 1)`` column, from the given or the stored coefficients."""
+        a = self.coeff_cos if coeff_cos is None else _column(coeff_cos)
+        b = self.coeff_sin if coeff_sin is None else _column(coeff_sin)
+        return self.basis_cos @ a + self.basis_sin @ b
 
-    def compute_E_batched(self, actions: np.ndarray):
-        """actions [num_envs, 2M] (cos coefficients then sin) -> E_ext [num_envs, N_mesh]."""
-        a = np.asarray(actions, dtype=float)
-        M = self.max_mode
-        return a[:, :M] @ self.basis_cos.T + a[:, M:] @ self.basis_sin.T
+    def compute_E_batched(self, actions):
+        """``[num_envs, 2 max_mode]`` actions (cos half, then sin half) -> ``[num_envs, N_mesh]``."""
+        act = np.asarray(actions, dtype=float)
+        m = self.max_mode
+        return act[:, :m] @ self.basis_cos.T + act[:, m:] @ self.basis_sin.T

@@ -1,113 +1,126 @@
-"""`Reward` with the interface of ``src/control/rl/reward.py:5-76``.
+"""Reward terms of the control problem, with the public surface of the reference's `Reward`
+(``src/control/rl/reward.py:5-76``) and of the helpers it calls (``src/control/objective.py:8-35``).
 
-The electric-energy reduction ``0.5 * sum(E_mesh^2) * dx`` (``src/control/objective.py:20-35``: CIC
-forced, no N/L factor) is evaluated on the device through ``pic_eval_field`` -- deposit the
-given state's positions, solve, reduce -- instead of a NumPy ``compute_E`` with freshly built
-dense matrices.  The phase-space histogram / KL diagnostic (objective.py:8-18) is a logging-only
-quantity and stays a NumPy histogram on the host.
+What the trainers use (ddpg.py:344,381,455; ppo.py; sac.py) is
+
+    reward = alpha * max(1 - PE / r_pe_n, 0) + beta * max(1 - IE / r_ie_n, 0)
+    PE = 0.5 * sum(E_mesh(state)^2) * dx            (CIC, no N/L factor; objective.py:33)
+    IE = sum(action^2) * L / 4                      (reward.py:52-54)
+    r_pe_n = 1, r_ie_n = IE(ones(n_actions))        (reward.py:32-33)
+
+`PE` needs a deposit + Poisson solve of the given state; here that evaluation runs on the device
+(`pic_eval_field` through a cached single-environment probe handle) instead of a NumPy `compute_E`
+with freshly built dense operators.  When the state is the environment's current one, the step has
+already produced the same number (`PIC.get_reward_electric_energy`, `BatchedPIC.energies()[2]`) and
+`Reward.reward_from_energy` turns it into the reward without another deposit.
+
+The phase-space histogram / KL divergence (objective.py:8-18) is a logged diagnostic
+(run_wo_oc.py:121), never part of `compute_reward`; it stays a host histogram.
 """
-from typing import Optional
-
 import numpy as np
 
 from .. import _abi
+from .._params import ParamMixin
 
-_EPS = 1e-12
-_probe_cache = {}
+_TINY = 1e-12
+_probes = {}
 
 
 def _probe(N, N_mesh, L, n0, device=0):
-    """One single-environment handle per problem shape, used only for field evaluation."""
+    """Single-environment handle used only to evaluate fields of host-supplied states."""
     key = (int(N), int(N_mesh), float(L), float(n0), int(device))
-    h = _probe_cache.get(key)
-    if h is None:
-        if len(_probe_cache) > 8:
-            _probe_cache.pop(next(iter(_probe_cache))).close()
-        h = _abi.Handle(N, N_mesh, 1, L, n0, 1.0, 5.0, "float64", None, "CIC", device)
-        _probe_cache[key] = h
-    return h
+    if key not in _probes:
+        while len(_probes) >= 8:                      # keep the cache small: handles own device memory
+            _probes.pop(next(iter(_probes))).close()
+        _probes[key] = _abi.Handle(key[0], key[1], 1, key[2], key[3], 1.0, 5.0, "float64", None, "CIC", key[4])
+    return _probes[key]
 
 
 def estimate_f(state, N_mesh, L, vmin, vmax, n0):
-    """Phase-space density on an N_mesh x N_mesh grid (objective.py:8-14)."""
-    N = state.shape[0] // 2
-    dx = L / N_mesh
-    dv = (vmax - vmin) / N_mesh
-    hist, _, _ = np.histogram2d(state[:N].ravel(), state[N:].ravel(), bins=[N_mesh, N_mesh], density=False,
-                                range=np.array([[0, L], [vmin, vmax]]))
-    hist *= n0 / dx / dv / N
-    return hist
+    """Phase-space density f(x, v) on an N_mesh x N_mesh grid, normalised so that sum(f) dx dv = n0."""
+    n_part = state.shape[0] // 2
+    cell = (L / N_mesh) * ((vmax - vmin) / N_mesh)
+    counts = np.histogram2d(state[:n_part].ravel(), state[n_part:].ravel(), bins=[N_mesh, N_mesh],
+                            range=[[0, L], [vmin, vmax]])[0]
+    return counts * (n0 / cell / n_part)
 
 
 def estimate_KL_divergence(f, feq, dx=0.1, dv=0.04):
-    """sum rel_entr(f, feq + eps) dx dv (objective.py:16-18) without scipy."""
-    q = feq + _EPS
-    with np.errstate(divide="ignore", invalid="ignore"):
-        t = np.where(f > 0, f * np.log(f / q), 0.0)
-    t = np.where((f > 0) & (q <= 0), np.inf, t)
-    return np.sum(t) * dx * dv
+    """sum_ij f log(f / (feq + 1e-12)) dx dv with the convention 0 log 0 = 0 (scipy's rel_entr)."""
+    q = feq + _TINY
+    terms = np.zeros_like(f, dtype=float)
+    pos = f > 0
+    terms[pos] = f[pos] * np.log(f[pos] / q[pos])
+    return terms.sum() * dx * dv
 
 
 def estimate_electric_energy(state, E_external, N_mesh, L, n0, device=0):
-    """0.5 * sum((E_mesh + E_ext)^2) * dx for the positions in ``state[:N]`` (objective.py:20-35)."""
-    state = np.asarray(state, dtype=np.float64)
-    N = state.shape[0] // 2
-    ext = None if E_external is None else np.asarray(E_external, dtype=np.float64).reshape(-1)
-    _, _, pe = _probe(N, N_mesh, L, n0, device).eval_field(state[:N].reshape(1, N), ext)
-    return float(pe[0])
+    """0.5 * sum((E_mesh + E_external)^2) * dx for the positions stored in ``state[:N]``."""
+    state = np.asarray(state, dtype=np.float64).reshape(-1)
+    n_part = state.shape[0] // 2
+    ext = None if E_external is None else np.asarray(E_external, dtype=np.float64).reshape(1, -1)
+    half_sum = _probe(n_part, N_mesh, L, n0, device).eval_field(state[:n_part].reshape(1, n_part), ext)[2]
+    return float(half_sum[0])
 
 
-class Reward:
+def input_energy(actions, L):
+    return np.sum(np.asarray(actions) ** 2) * L * 0.25
+
+
+def _clipped(value, scale):
+    return max(1.0 - value / scale, 0)
+
+
+def _tanh_score(value, scale):
+    return np.tanh(1 - np.sqrt(value / scale))
+
+
+class Reward(ParamMixin):
     def __init__(self, init_state, N_mesh=500, L=50.0, vmin=-25.0, vmax=25.0, n0=1.0, alpha=1.0, beta=1.0,
                  n_actions=10, device=0):
-        self.feq = estimate_f(init_state, N_mesh, L, vmin, vmax, n0)
         self.init_state = init_state
-        self.N_mesh, self.L, self.vmin, self.vmax, self.n0 = N_mesh, L, vmin, vmax, n0
-        self.n_actions = n_actions
-        self.alpha, self.beta = alpha, beta
+        self.N_mesh, self.L, self.n0 = N_mesh, L, n0
+        self.vmin, self.vmax = vmin, vmax
+        self.alpha, self.beta, self.n_actions = alpha, beta, n_actions
         self.device = device
-        self.r_pe_n = 1.0                                                    # reward.py:32
-        self.r_ie_n = self.compute_input_energy(np.ones(n_actions))          # reward.py:33
-
-    def update_params(self, **kwargs):
-        for key, val in kwargs.items():
-            if hasattr(self, key) and val is not None:
-                setattr(self, key, val)
+        self.r_pe_n = 1.0
+        self.r_ie_n = input_energy(np.ones(n_actions), L)
+        self.reinit()
 
     def reinit(self):
+        """Recompute the reference distribution of the KL diagnostic from ``init_state``."""
         self.feq = estimate_f(self.init_state, self.N_mesh, self.L, self.vmin, self.vmax, self.n0)
 
+    # -- the three cost terms ------------------------------------------------------------------
     def compute_kl_divergence(self, state):
         f = estimate_f(state, self.N_mesh, self.L, self.vmin, self.vmax, self.n0)
         return estimate_KL_divergence(f, self.feq, self.L / self.N_mesh, (self.vmax - self.vmin) / self.N_mesh)
 
-    def compute_electric_energy(self, state, E_external: Optional[np.ndarray] = None):
-        return estimate_electric_energy(np.asarray(state).reshape(-1, 1), E_external, self.N_mesh, self.L, self.n0,
-                                        self.device)
+    def compute_electric_energy(self, state, E_external=None):
+        return estimate_electric_energy(state, E_external, self.N_mesh, self.L, self.n0, self.device)
 
     def compute_input_energy(self, actions):
-        return np.sum(np.asarray(actions) ** 2) * self.L * 0.25
+        return input_energy(actions, self.L)
 
     def compute_cost(self, state, action):
-        return self.compute_kl_divergence(state), self.compute_electric_energy(state), self.compute_input_energy(action)
+        return (self.compute_kl_divergence(state), self.compute_electric_energy(state),
+                self.compute_input_energy(action))
 
-    def compute_reward_kl_divergence(self, state):
-        return np.tanh(1 - np.sqrt(self.compute_kl_divergence(state) / 25))
-
-    def compute_reward_electric_energy(self, state, E_external=None):
-        return np.tanh(1 - np.sqrt(self.compute_electric_energy(state, E_external) / 10.0))
-
-    def compute_reward_input_energy(self, action):
-        return np.tanh(1 - np.sqrt(self.compute_input_energy(action) / 50.0))
-
+    # -- rewards -------------------------------------------------------------------------------
     def compute_reward(self, state, E_external=None):
-        """reward.py:71-76 -- note the second argument is the ACTION vector there."""
-        r_pe = max(1.0 - self.compute_electric_energy(state) / self.r_pe_n, 0)
-        r_ie = max(1.0 - self.compute_input_energy(E_external) / self.r_ie_n, 0)
-        return r_pe * self.alpha + r_ie * self.beta
+        """The trainers' reward; note that the second argument is the ACTION vector (reward.py:71-76)."""
+        return self.reward_from_energy(self.compute_electric_energy(state), E_external)
 
     def reward_from_energy(self, pe_reward, action):
-        """Same value from a PE_reward the step already produced (no second deposit)."""
-        r_pe = max(1.0 - float(pe_reward) / self.r_pe_n, 0)
-        r_ie = max(1.0 - self.compute_input_energy(action) / self.r_ie_n, 0)
-        return r_pe * self.alpha + r_ie * self.beta
+        """Same value from a field energy the step already produced (no second deposit)."""
+        return (self.alpha * _clipped(float(pe_reward), self.r_pe_n)
+                + self.beta * _clipped(self.compute_input_energy(action), self.r_ie_n))
+
+    def compute_reward_kl_divergence(self, state):
+        return _tanh_score(self.compute_kl_divergence(state), 25)
+
+    def compute_reward_electric_energy(self, state, E_external=None):
+        return _tanh_score(self.compute_electric_energy(state, E_external), 10.0)
+
+    def compute_reward_input_energy(self, action):
+        return _tanh_score(self.compute_input_energy(action), 50.0)

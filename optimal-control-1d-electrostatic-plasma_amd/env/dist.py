@@ -9,6 +9,8 @@ draws are kept as arrays, not Python lists, which is what makes N = 1e6 usable.
 """
 import numpy as np
 
+from .._params import ParamMixin
+
 
 def _gaussian_pdf(v, vb, sigma):
     # dist.py:66-68 / 147-149
@@ -31,7 +33,7 @@ def _draw_until(count_reached, L, vb, sigma, batch):
     return np.concatenate(xs), np.concatenate(vs)
 
 
-class _Sampler:
+class _Sampler(ParamMixin):
     def initialize(self, n_samples):
         state = self.rejection_sampling(n_samples)
         self.x_init = state[:, 0]
@@ -45,11 +47,6 @@ class _Sampler:
 
     def get_init_state(self):
         return np.concatenate([self.x_init.copy().reshape(-1, 1), self.v_init.copy().reshape(-1, 1)], axis=0)
-
-    def update_params(self, **kwargs):
-        for key, val in kwargs.items():
-            if hasattr(self, key) and val is not None:
-                setattr(self, key, val)
 
 
 class TwoStream(_Sampler):
