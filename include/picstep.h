@@ -126,6 +126,12 @@ int pic_step_actions(pic_handle* h, const double* actions, int mem_kind, int nst
  * src/control/rl/ddpg.py:369-371 is (-re, +im). */
 int pic_get_modes(pic_handle* h, int max_mode, double* re, double* im, int mem_kind);
 
+/* Phase-space histogram behind the KL diagnostic, estimate_f (src/control/objective.py:8-14):
+ * counts[num_envs][nbins][nbins] (host, uint32) of the current particles on
+ * np.histogram2d's bins for range [[0, L], [vmin, vmax]] -- same edge rules (edges lo + i*step,
+ * last edge inclusive, out-of-range values dropped).  f = counts * n0 / dx / dv / N on the host. */
+int pic_phase_histogram(pic_handle* h, int nbins, double vmin, double vmax, uint32_t* counts);
+
 /* Per-kernel timing with HIP events on the handle's stream (bench.py's roofline leg).
  * kinds: 0..3 = sweeps A..D, 4 = field solve. ms_sum / launches are arrays of 8. */
 int pic_profile(pic_handle* h, int enable);

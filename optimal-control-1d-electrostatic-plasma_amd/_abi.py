@@ -54,6 +54,7 @@ SIGNATURES = {
     "pic_set_actuator": [_vp, C.c_int, _vp, _vp],
     "pic_step_actions": [_vp, _vp, C.c_int, C.c_int],
     "pic_get_modes": [_vp, C.c_int, _vp, _vp, C.c_int],
+    "pic_phase_histogram": [_vp, C.c_int, C.c_double, C.c_double, _vp],
     "pic_stream_probe": [_vp, C.c_int, _dp],
     "pic_sync": [_vp],
     "pic_bad_count": [_vp, _i64p],
@@ -262,6 +263,11 @@ class Handle:
         im = np.empty_like(re)
         self._chk(self.lib.pic_get_modes(self._h, int(max_mode), _ptr(re), _ptr(im), PIC_HOST))
         return re + 1j * im
+
+    def phase_histogram(self, nbins, vmin, vmax):
+        counts = np.zeros((self.num_envs, int(nbins), int(nbins)), dtype=np.uint32)
+        self._chk(self.lib.pic_phase_histogram(self._h, int(nbins), float(vmin), float(vmax), _ptr(counts)))
+        return counts
 
     def stream_probe(self, repeats=10):
         g = C.c_double()

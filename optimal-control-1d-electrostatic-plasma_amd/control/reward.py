@@ -39,10 +39,11 @@ def _probe(N, N_mesh, L, n0, device=0):
 def estimate_f(state, N_mesh, L, vmin, vmax, n0):
     """Phase-space density f(x, v) on an N_mesh x N_mesh grid, normalised so that sum(f) dx dv = n0."""
     n_part = state.shape[0] // 2
-    cell = (L / N_mesh) * ((vmax - vmin) / N_mesh)
+    dx, dv = L / N_mesh, (vmax - vmin) / N_mesh
     counts = np.histogram2d(state[:n_part].ravel(), state[n_part:].ravel(), bins=[N_mesh, N_mesh],
                             range=[[0, L], [vmin, vmax]])[0]
-    return counts * (n0 / cell / n_part)
+    counts *= n0 / dx / dv / n_part          # same operand order as objective.py:13
+    return counts
 
 
 def estimate_KL_divergence(f, feq, dx=0.1, dv=0.04):

@@ -761,6 +761,33 @@ __global__ __launch_bounds__(BLOCK) void modes_kernel(const double* __restrict__
   }
 }
 
+// np.histogram2d bin of `val` for edges = np.linspace(lo, hi, nb + 1) (edges[i] = lo + i*step, last = hi):
+// searchsorted(edges, val, 'right') - 1, the last edge inclusive, -1 for values outside [lo, hi].
+__device__ __forceinline__ int hist_bin(double val, double lo, double hi, double step, int nb) {
+  if (!(val >= lo && val <= hi)) return -1;
+  int b = (int)((val - lo) / step);
+  b = b < 0 ? 0 : (b > nb - 1 ? nb - 1 : b);
+  auto edge = [&](int i) { return i == nb ? hi : lo + (double)i * step; };
+  while (b > 0 && val < edge(b)) --b;
+  while (b < nb - 1 && val >= edge(b + 1)) ++b;
+  return b;
+}
+
+// Phase-space histogram of the KL diagnostic (src/control/objective.py:8-14): counts[env][ix][iv].
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void phase_hist_kernel(const T* __restrict__ x, const T* __restrict__ v,
+                                                           unsigned* __restrict__ counts, long long N, long long ld,
+                                                           int nb, double L, double vmin, double vmax) {
+  const int env = blockIdx.y;
+  const double sx = (L - 0.0) / nb, sv = (vmax - vmin) / nb;      // np.linspace step = (stop - start) / div
+  unsigned* c = counts + (size_t)env * nb * nb;
+  for (long long i = (long long)blockIdx.x * BLOCK + threadIdx.x; i < N; i += (long long)gridDim.x * BLOCK) {
+    const int ix = hist_bin((double)x[(size_t)env * ld + i], 0.0, L, sx, nb);
+    const int iv = hist_bin((double)v[(size_t)env * ld + i], vmin, vmax, sv, nb);
+    if (ix >= 0 && iv >= 0) atomicAdd(&c[(size_t)ix * nb + iv], 1u);
+  }
+}
+
 // Streaming ceiling of this box for the sweeps' access shape: read two arrays, write two arrays, 16 B
 // per lane, same grid -- what a sweep would take if it did no arithmetic at all.
 __global__ __launch_bounds__(BLOCK) void stream_probe_kernel(double2* __restrict__ a, double2* __restrict__ b,
@@ -1482,6 +1509,34 @@ int pic_get_modes(pic_handle* h, int max_mode, double* re, double* im, int mem_k
   if (re) HIPCHK(h, hipMemcpyAsync(re, dre, nb, k, h->stream));
   if (im) HIPCHK(h, hipMemcpyAsync(im, dim_, nb, k, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
+  return PIC_OK;
+}
+
+int pic_phase_histogram(pic_handle* h, int nbins, double vmin, double vmax, uint32_t* counts) {
+  if (!h || !counts || nbins < 1 || nbins > 4096 || !(vmax > vmin))
+    return fail(h, PIC_EINVAL, "pic_phase_histogram: need counts, 1 <= nbins <= 4096, vmax > vmin");
+  if (!h->has_state) return fail(h, PIC_ESTATE, "pic_phase_histogram: call pic_reset first");
+  HIPCHK(h, hipSetDevice(h->cfg.device_id));
+  const size_t nb = (size_t)h->cfg.num_envs * nbins * nbins * sizeof(unsigned);
+  unsigned* d = nullptr;
+  HIPCHK(h, hipMalloc((void**)&d, nb));
+  hipError_t e = hipMemsetAsync(d, 0, nb, h->stream);
+  long long gx = (h->cfg.N + BLOCK - 1) / BLOCK;
+  if (gx > 2048) gx = 2048;
+  dim3 grid((unsigned)gx, h->cfg.num_envs);
+  if (e == hipSuccess) {
+    if (h->cfg.particle_dtype == PIC_F64)
+      hipLaunchKernelGGL(phase_hist_kernel<double>, grid, dim3(BLOCK), 0, h->stream, (const double*)h->x,
+                         (const double*)h->v, d, h->cfg.N, h->ld, nbins, h->cfg.L, vmin, vmax);
+    else
+      hipLaunchKernelGGL(phase_hist_kernel<float>, grid, dim3(BLOCK), 0, h->stream, (const float*)h->x,
+                         (const float*)h->v, d, h->cfg.N, h->ld, nbins, h->cfg.L, vmin, vmax);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(counts, d, nb, hipMemcpyDeviceToHost, h->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+  hipFree(d);
+  if (e != hipSuccess) return fail(h, PIC_EHIP, std::string("pic_phase_histogram: ") + hipGetErrorString(e));
   return PIC_OK;
 }
 

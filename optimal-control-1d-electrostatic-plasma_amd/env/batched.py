@@ -102,6 +102,22 @@ class BatchedPIC:
         ek = self.modes(max_mode)
         return np.concatenate([-ek.real, ek.imag], axis=1)
 
+    def phase_density(self, nbins: int, vmin: float = -25.0, vmax: float = 25.0):
+        """estimate_f (src/control/objective.py:8-14) for every environment, [num_envs, nbins, nbins]:
+        the histogram is counted on the device, the normalisation n0/dx/dv/N applied here."""
+        counts = self._h.phase_histogram(nbins, vmin, vmax).astype(np.float64)
+        dx, dv = self.L / nbins, (vmax - vmin) / nbins
+        counts *= self.n0 / dx / dv / self.N
+        return counts
+
+    def kl_divergence(self, feq, vmin: float = -25.0, vmax: float = 25.0):
+        """Reward.compute_kl_divergence (reward.py:43-46) per environment against `feq` [nbins, nbins]."""
+        from ..control.reward import estimate_KL_divergence
+        nb = feq.shape[-1]
+        f = self.phase_density(nb, vmin, vmax)
+        return np.array([estimate_KL_divergence(f[e], feq, self.L / nb, (vmax - vmin) / nb)
+                         for e in range(self.num_envs)])
+
     def stream_probe(self, repeats=10):
         """GB/s of a read-2-arrays / write-2-arrays copy with the sweeps' grid on this device."""
         return self._h.stream_probe(repeats)

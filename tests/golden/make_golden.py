@@ -186,6 +186,21 @@ def main():
     ks, Ek = compute_E_k_spectrum(1.0, L, L / 250, 250, snap.copy(), False)
     save("g9_spectrum", ks=ks[:8], Ek=Ek[:8, :])
 
+    # ---- G11: phase-space histogram + KL diagnostic (objective.py:8-18, reward.py:43-46) ----
+    from src.control.objective import estimate_f
+    st0 = np.concatenate([d["x0_raw"].reshape(-1, 1), d["v0_raw"].reshape(-1, 1)], 0)
+    st1 = np.concatenate([d["x_100"], d["v_100"]], 0)
+    # edge cases for the binning: values on interior edges, on both outer edges and outside the range
+    st2 = st1.copy()
+    Np = st2.shape[0] // 2
+    st2[:6, 0] = [0.0, L, 25.0, L / 64 * 3, np.nextafter(L, 0.0), 12.5]
+    st2[Np:Np + 6, 0] = [-25.0, 25.0, 0.0, 50.0 / 64 * 5 - 25.0, 30.0, -26.0]
+    rw = Reward(st0, 64, L, -25.0, 25.0, 1.0, 1.0, 1.0)
+    save("g11_phase_hist", L=L, nbins=64, vmin=-25.0, vmax=25.0, n0=1.0, st0=st0, st1=st1, st2=st2,
+         f0=estimate_f(st0, 64, L, -25.0, 25.0, 1.0), f1=estimate_f(st1, 64, L, -25.0, 25.0, 1.0),
+         f2=estimate_f(st2, 64, L, -25.0, 25.0, 1.0), kl1=rw.compute_kl_divergence(st1),
+         kl2=rw.compute_kl_divergence(st2), kl0=rw.compute_kl_divergence(st0))
+
     # ---- samplers (pins the product's own dist.py to the reference's RNG use) --
     np.random.seed(7)
     ts = TwoStream(v0=3.0, sigma=1.0, n_samples=2001, L=L)

@@ -411,6 +411,23 @@ def test_device_actuator_and_feedback_modes(oc, po):
     assert rel_err(Ek[1:M + 1, 0], ek[0]) < 1e-10
 
 
+def test_phase_histogram_and_kl_on_device(oc):
+    """estimate_f / compute_kl_divergence with the histogram counted on the device; the
+    golden states include values on interior edges, on both outer edges and outside the range."""
+    g = load_golden("g11_phase_hist")
+    nb, L = int(g["nbins"]), float(g["L"])
+    Np = g["st1"].shape[0] // 2
+    env = oc.BatchedPIC(3, Np, 64, L=L, dt=0.1)
+    xs = np.stack([g["st" + k][:Np, 0] for k in ("0", "1", "2")])
+    vs = np.stack([g["st" + k][Np:, 0] for k in ("0", "1", "2")])
+    env._h.set_particles(xs, vs)               # keep the raw values (reset would wrap x = L to 0)
+    f = env.phase_density(nb, -25.0, 25.0)
+    for e, k in enumerate(("0", "1", "2")):
+        assert np.array_equal(f[e], g["f" + k]), k
+    kl = env.kl_divergence(g["f0"], -25.0, 25.0)
+    assert np.allclose(kl, [float(g["kl0"]), float(g["kl1"]), float(g["kl2"])], rtol=1e-12, atol=1e-15)
+
+
 def test_edge_sizes(oc, po):
     """Ragged and extreme shapes: fewer particles than one tile, one particle, the largest mesh,
     a mesh over the LDS limit, zero steps."""

@@ -77,6 +77,18 @@ def test_reward_host_pieces():
     assert r.compute_input_energy(np.ones(10)) == 10 * 50.0 * 0.25
 
 
+def test_kl_diagnostic_matches_golden():
+    g = load_golden("g11_phase_hist")
+    nb, L = int(g["nbins"]), float(g["L"])
+    rw = Reward.__new__(Reward)        # host-only pieces: no device handle needed
+    rw.init_state, rw.N_mesh, rw.L, rw.vmin, rw.vmax, rw.n0 = g["st0"], nb, L, float(g["vmin"]), float(g["vmax"]), 1.0
+    rw.reinit()
+    for k in ("0", "1", "2"):
+        f = estimate_f(g["st" + k], nb, L, -25.0, 25.0, 1.0)
+        assert np.array_equal(f, g["f" + k]), k
+        assert abs(rw.compute_kl_divergence(g["st" + k]) - float(g["kl" + k])) <= 1e-12 * max(1.0, abs(float(g["kl" + k])))
+
+
 def test_header_symbols_are_exported(lib_path):
     hdr = open(os.path.join(ROOT, "include", "picstep.h")).read()
     declared = set(re.findall(r"^(?:int|const char\*)\s+(pic_[A-Za-z_]+)\s*\(", hdr, re.M))
