@@ -5,24 +5,31 @@
 // One environment step = PIC.update_state of the reference (src/env/pic.py:131-146), i.e. the
 // Yoshida-4 composition of src/env/integration.py:60-75 restated as kick/drift sub-stages:
 //
-//   sweep A : q1 = x + (c1 v) dt                              deposit(q1)
-//   solve   : E = field(n) + E_ext
-//   sweep B : p1 = v + (d1 (-E(q1))) dt ; q2 = q1 + (c2 p1) dt ; deposit(q2) ; store q2,p1
+//   [sweep A: q1 = x + (c1 v) dt ; deposit(q1)]   -- normally NOT run: the previous sweep D (or the
+//                                                    reset sweep) has already deposited this q1
+//   solve   : E = field(deposit of q1) + E_ext
+//   sweep B : p1 = v + (d1 (-E(q1))) dt ; q2 = q1 + (c2 p1) dt ; deposit(q2) ; store q2, p1
 //   solve
 //   sweep C : p2 = p1 + (d2 (-E(q2))) dt ; q3 = q2 + (c3 p2) dt ; deposit(q3) ; store
 //   solve
 //   sweep D : p3 = p2 + (d3 (-E(q3))) dt ; q4 = q3 + (c4 p3) dt ; x' = mod(q4, L) ; deposit(x') ;
-//             KE partials ; store x', p3
+//             KE partials ; store x', p3 ; deposit(next q1 = x' + (c1 p3) dt) into a second mesh
 //   solve   : n, E_mesh (no E_ext), phi, KE, PE, PE_reward        (pic.py:145-146, util.py:119-147)
+//
+// 7 launches and 3 read+write passes over the particles per step (96 B per particle-step in fp64).
 //
 // Arithmetic inside a sub-stage keeps the reference's operand order and is compiled with
 // -ffp-contract=off so that fp64 results track NumPy to rounding (tests/ hold the bounds).
 //
-// Deposit: every workgroup owns LDS copies of its environment's mesh (one per wave, `R` copies),
-// accumulates with LDS float atomics (ds_add_f64 / ds_add_f32), then stores its partial mesh as one
-// row of a slab [env][block][Ng] with plain coalesced stores.  The field-solve kernel sums the
-// rows in block order (no global atomics, no memset between sweeps), scales to a density and
-// solves the periodic Poisson problem with two prefix scans (DESIGN.md "Field solve").
+// Deposit: every workgroup owns LDS copies of its environment's mesh (one per wave, `R` copies, two
+// sets in sweep D), accumulates with LDS float atomics (ds_add_f64; ds_add_f32 is selectable but
+// measured ~4x slower), then stores its partial mesh as one row of a slab [env][block][Ng] with plain
+// coalesced stores.  The field-solve kernel sums the rows in a fixed order (no global atomics, no
+// memset between sweeps), scales to a density and solves the periodic Poisson problem with two prefix
+// scans.
+//
+// Compile-time switches (all off in the shipped build; results of each in profiles/experiments_r1.md):
+// PIC_EXP_* are timing/diagnostic experiments, PIC_PIPE / PIC_TILES alternative loop forms.
 
 #include <hip/hip_runtime.h>
 

@@ -411,6 +411,21 @@ def test_device_actuator_and_feedback_modes(oc, po):
     assert rel_err(Ek[1:M + 1, 0], ek[0]) < 1e-10
 
 
+def test_feedback_control_loop_on_device():
+    """run_feedback.py-shaped closed loop through modes -> action -> device actuator -> step: the
+    controlled two-stream plasma must stay far below the free one's saturated field energy."""
+    import importlib.util
+    import os
+    from conftest import ROOT
+    spec = importlib.util.spec_from_file_location("feedback_control", os.path.join(ROOT, "examples", "feedback_control.py"))
+    fc = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fc)
+    pf, pc, effort = fc.run(num_envs=2, N=20000, steps=300, verbose=False)
+    assert pf[-75:].mean() > 2.0                       # the instability did develop without control
+    assert pc[-75:].mean() < 0.2 * pf[-75:].mean()     # and was suppressed with it
+    assert effort.max() < 1.25                         # inside the trainers' action range (|a| <= 1.25)
+
+
 def test_phase_histogram_and_kl_on_device(oc):
     """estimate_f / compute_kl_divergence with the histogram counted on the device; the
     golden states include values on interior edges, on both outer edges and outside the range."""
