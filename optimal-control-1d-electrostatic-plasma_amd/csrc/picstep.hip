@@ -219,6 +219,10 @@ template <typename T, typename A, int SHAPE, int STAGE>
 __device__ __forceinline__ void push_one(T& xq, T& vp, const T* __restrict__ Es, A* __restrict__ acc,
                                          A* __restrict__ acc2, T L, T dx, T rdx, T dt, T c_prev, T c_cur, T d_cur,
                                          T c_next, int Ng, double& ke, unsigned& bad) {
+#if defined(PIC_EXP_LEVEL) && PIC_EXP_LEVEL <= 1      // timing experiment: stream only (results are wrong)
+  xq = xq + T(0); vp = vp + T(0);
+  return;
+#endif
   T w[3];
   T xw;
   int j;
@@ -228,12 +232,20 @@ __device__ __forceinline__ void push_one(T& xq, T& vp, const T* __restrict__ Es,
   } else if (STAGE == ST_B || STAGE == ST_C || STAGE == ST_D) {
     if (STAGE == ST_B) q = q + (c_prev * p) * dt;               // q1 again (it is never stored)
     locate<T, SHAPE>(q, L, dx, rdx, Ng, xw, j, w, bad);
+#if defined(PIC_EXP_LEVEL) && PIC_EXP_LEVEL == 2      // timing experiment: arithmetic only, no LDS traffic
+    T E = w[0] * T(0.25) + w[1] * T(0.5) + T(j) * T(1e-30);
+#else
     T E = gather_field<T, SHAPE>(Es, j, w);                     // util.py:105 / pic.py:120
+#endif
     p = p + (d_cur * (-E)) * dt;                                // integration.py:32, pic.py:127
     q = q + (c_cur * p) * dt;                                   // integration.py:42
   }
   locate<T, SHAPE>(q, L, dx, rdx, Ng, xw, j, w, bad);
+#if defined(PIC_EXP_LEVEL) && (PIC_EXP_LEVEL == 2 || PIC_EXP_LEVEL == 3)   // no deposit (3: gather kept)
+  asm volatile("" ::"v"(w[0]), "v"(w[1]), "v"(j));
+#else
   deposit<A, T, SHAPE>(acc, j, w);
+#endif
   if (STAGE == ST_D || STAGE == ST_REFRESH) {
     q = xw;                                                     // pic.py:139 (+ util.py:51)
     ke += (double)p * (double)p;
@@ -302,12 +314,17 @@ __global__ __launch_bounds__(BLOCK) void sweep_kernel(T* __restrict__ x, T* __re
 #ifdef PIC_EXP_STAMPB
   const unsigned long long sb0 = wall_clock64();
 #endif
-  for (int i = tid; i < nacc; i += BLOCK) acc_all[i] = A(0);
+#if defined(PIC_EXP_LEVEL) && PIC_EXP_LEVEL <= 0
+  constexpr bool kPrologue = false;      // timing experiment: no LDS zeroing / field tile / barrier
+#else
+  constexpr bool kPrologue = true;
+#endif
+  if (kPrologue) for (int i = tid; i < nacc; i += BLOCK) acc_all[i] = A(0);
 #ifdef PIC_EXP_STAMPB
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   const unsigned long long sbz = wall_clock64();
 #endif
-  if (kGather) {
+  if (kGather && kPrologue) {
     const double* Ee = Ef + (size_t)env * Ng;
     for (int i = tid; i < stride; i += BLOCK) {
       int node = i - OFF;
@@ -319,7 +336,7 @@ __global__ __launch_bounds__(BLOCK) void sweep_kernel(T* __restrict__ x, T* __re
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   const unsigned long long sbe = wall_clock64();
 #endif
-  __syncthreads();
+  if (kPrologue) __syncthreads();
 
   const int rep = (tid >> 6) & (a.R - 1);
   A* acc = acc_all + (size_t)rep * stride;
@@ -507,6 +524,10 @@ __global__ __launch_bounds__(BLOCK) void sweep_kernel(T* __restrict__ x, T* __re
   const unsigned long long sb3 = wall_clock64();      // every wave's loop is done
 #endif
 
+#if defined(PIC_EXP_LEVEL) && PIC_EXP_LEVEL <= -1
+  if (ke < -1.0) part[0] = ke;           // timing experiment: no flush, no KE reduction
+  return;
+#endif
   const size_t rowi = ((size_t)env * a.nblk + blk) * Ng;
   flush_mesh<A, SHAPE>(acc_all, a.R, stride, Ng, part + rowi);
   if (kDual) flush_mesh<A, SHAPE>(acc2_all, a.R, stride, Ng, part2 + rowi);
