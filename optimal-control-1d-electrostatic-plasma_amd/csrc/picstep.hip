@@ -346,9 +346,6 @@ __global__ __launch_bounds__(BLOCK) void sweep_kernel(T* __restrict__ x, T* __re
 
   T* xe = x + (size_t)env * a.ld;
   T* ve = v + (size_t)env * a.ld;
-  const long long begin = (long long)blk * a.chunk;
-  long long end = begin + a.chunk;
-  if (end > a.N) end = a.N;
   const long long step = (long long)BLOCK * VEC;
 
   double ke = 0.0;
@@ -356,6 +353,12 @@ __global__ __launch_bounds__(BLOCK) void sweep_kernel(T* __restrict__ x, T* __re
 #ifdef PIC_EXP_STAMPB
   const unsigned long long sb1 = wall_clock64();
 #endif
+  // A workgroup owns the runs blk, blk + nblk, blk + 2 nblk, ... of `chunk` particles of its environment.
+  // chunk = ceil(N / nblk) gives every workgroup one contiguous region; a chunk of a few tiles interleaves
+  // the workgroups of an environment, so that the addresses in flight form a compact moving window.
+  for (long long begin = (long long)blk * a.chunk; begin < a.N; begin += (long long)a.nblk * a.chunk) {
+  long long end = begin + a.chunk;
+  if (end > a.N) end = a.N;
   long long i = begin + (long long)tid * VEC;
 #if PIC_PIPE == 0
   // PIC_TILES tiles per lane per iteration: all their loads are issued before the first particle is
@@ -516,6 +519,7 @@ __global__ __launch_bounds__(BLOCK) void sweep_kernel(T* __restrict__ x, T* __re
       if (kStoreV) ve[k] = pv;
     }
   }
+  }   // runs
 #ifdef PIC_EXP_STAMPB
   const unsigned long long sb2 = wall_clock64();      // this wave's loop is done
 #endif
@@ -1119,6 +1123,10 @@ int pic_create(const pic_config* cfg, pic_handle** out) {
   chunk = (chunk + tile - 1) / tile * tile;
   nblk = (cfg->N + chunk - 1) / chunk;
   if (nblk > 65535) { delete h; return fail(nullptr, PIC_EINVAL, "pic_create: blocks_per_env too large"); }
+  if (const char* rt = getenv("PICSTEP_RUN_TILES")) {      // experiment knob: interleave runs of this many tiles
+    const long long k = atoll(rt);
+    if (k > 0) chunk = k * tile;
+  }
   h->chunk = chunk;
   h->nblk = (int)nblk;
 
