@@ -845,6 +845,13 @@ __global__ __launch_bounds__(BLOCK) void stream_probe_kernel(double2* __restrict
 // ---------------------------------------------------------------------------------------------
 // Host side
 // ---------------------------------------------------------------------------------------------
+// one captured environment step (7 kernel nodes), valid for one external-field pointer and start parity
+struct StepGraph {
+  hipGraphExec_t exec = nullptr;
+  const double* ext = nullptr;
+  int parity = 0, parity_out = 0;
+};
+
 struct pic_handle {
   pic_config cfg{};
   int vec = 2;
@@ -871,6 +878,8 @@ struct pic_handle {
   double* part = nullptr;         // [env][nblk][Ng] deposit of the sweep just run
   double* part2 = nullptr;        // [env][nblk][Ng] deposit of the NEXT step's q1 (sweeps D / REFRESH)
   int sweep_parity = 0;           // direction of the next push sweep
+  bool use_graph = false;         // replay steps from hipGraphs (launch-bound sizes)
+  std::vector<StepGraph> graphs;
   bool q1_ready = false;          // part2 matches the stored particles, dt and c1: sweep A can be skipped
   double* ke_part = nullptr;      // [env][nblk]
   double* Ef = nullptr;           // field used by the gathers (E + E_ext)
@@ -1156,6 +1165,12 @@ int pic_create(const pic_config* cfg, pic_handle** out) {
                                    (int)h->solve_lds));
   CREATE_CHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
   {
+    // hipGraph replay of a step (PICSTEP_GRAPH=1).  Off by default: at N = 1e4 the 7 dependent kernels cost
+    // ~7 us each on the device whichever way they are launched (50.4 us/step eager, 53.9 us/step replayed).
+    const char* ug = getenv("PICSTEP_GRAPH");
+    h->use_graph = ug && atoi(ug) != 0;
+  }
+  {
     // group size: particles (x and v) of a group <= PICSTEP_GROUP_MB; 0 disables grouping
     const char* gm = getenv("PICSTEP_GROUP_MB");
     const char* ns = getenv("PICSTEP_STREAMS");
@@ -1228,6 +1243,8 @@ int pic_destroy(pic_handle* h) {
   for (void* b : bufs)
     if (b) hipFree(b);
   if (h->h_scal) hipHostFree(h->h_scal);
+  for (StepGraph& g : h->graphs)
+    if (g.exec) hipGraphExecDestroy(g.exec);
   for (hipStream_t st : h->wstreams) hipStreamDestroy(st);
   for (hipEvent_t ev : h->join_ev) hipEventDestroy(ev);
   if (h->fork_ev) hipEventDestroy(h->fork_ev);
@@ -1316,7 +1333,39 @@ int pic_step(pic_handle* h, const double* E_ext, int mem_kind, int nsteps) {
   if (G <= 0 || G >= E || h->wstreams.empty() || nsteps == 0) {
     Lane ln = whole(h);
     ln.parity = h->sweep_parity;
-    for (int s = 0; s < nsteps; ++s) one_step(ln, s > 0 || q1_ready);
+    for (int s = 0; s < nsteps; ++s) {
+      const bool have_q1 = s > 0 || q1_ready;
+      if (!h->use_graph || h->prof || !have_q1) {
+        one_step(ln, have_q1);
+        continue;
+      }
+      // Launch-bound regime (small environments): the 7 launches of a step are replayed from a hipGraph.
+      // A graph bakes in the kernel arguments, i.e. the external-field pointer and the direction parity
+      // the step starts with (it flips every step), so executables are cached per (ext, parity).
+      StepGraph* g = nullptr;
+      for (StepGraph& c : h->graphs)
+        if (c.exec && c.ext == ext && c.parity == ln.parity) { g = &c; break; }
+      if (!g) {
+        if (h->graphs.size() >= 8) {               // bounded cache: drop the oldest executable
+          hipGraphExecDestroy(h->graphs.front().exec);
+          h->graphs.erase(h->graphs.begin());
+        }
+        hipGraph_t graph = nullptr;
+        Lane cap = ln;
+        HIPCHK(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+        one_step(cap, true);
+        HIPCHK(h, hipStreamEndCapture(h->stream, &graph));
+        StepGraph ng;
+        ng.ext = ext; ng.parity = ln.parity; ng.parity_out = cap.parity;
+        hipError_t ge = hipGraphInstantiate(&ng.exec, graph, nullptr, nullptr, 0);
+        hipGraphDestroy(graph);
+        if (ge != hipSuccess) return fail(h, PIC_EHIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(ge));
+        h->graphs.push_back(ng);
+        g = &h->graphs.back();
+      }
+      HIPCHK(h, hipGraphLaunch(g->exec, h->stream));
+      ln.parity = g->parity_out;
+    }
     h->sweep_parity = ln.parity;
   } else {
     // Environments are independent: walk them in cache-sized groups, neighbouring groups on different
