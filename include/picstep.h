@@ -142,6 +142,12 @@ int pic_profile_read(pic_handle* h, double* ms_sum, int64_t* launches);
  * scratch arrays of the handle's particle footprint.  bench.py reports it next to the 8 TB/s spec. */
 int pic_stream_probe(pic_handle* h, int repeats, double* gbytes_per_s);
 
+/* Run all further work of this handle on the caller's HIP stream (a hipStream_t, e.g. torch's current
+ * stream) instead of the handle's own; NULL switches back.  The previous stream is drained first.  With
+ * device-pointer inputs/outputs (pic_step, pic_step_actions, pic_get_modes, pic_device_ptrs views) a
+ * control loop then stays stream-ordered with the caller's kernels and needs no host synchronisation. */
+int pic_set_stream(pic_handle* h, void* hip_stream);
+
 int pic_sync(pic_handle* h);
 /* Number of particle positions found non-finite or out of range by the last sweeps (0 = healthy). */
 int pic_bad_count(pic_handle* h, int64_t* count);

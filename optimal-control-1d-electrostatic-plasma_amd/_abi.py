@@ -56,6 +56,7 @@ SIGNATURES = {
     "pic_get_modes": [_vp, C.c_int, _vp, _vp, C.c_int],
     "pic_phase_histogram": [_vp, C.c_int, C.c_double, C.c_double, _vp],
     "pic_stream_probe": [_vp, C.c_int, _dp],
+    "pic_set_stream": [_vp, _vp],
     "pic_sync": [_vp],
     "pic_bad_count": [_vp, _i64p],
     "pic_last_error": [_vp],
@@ -257,6 +258,13 @@ class Handle:
 
     def step_actions_device(self, actions_ptr, nsteps=1):
         self._chk(self.lib.pic_step_actions(self._h, _ptr(int(actions_ptr)), PIC_DEVICE, int(nsteps)))
+
+    def set_stream(self, hip_stream):
+        """hip_stream: integer hipStream_t (e.g. torch.cuda.current_stream().cuda_stream), or 0/None."""
+        self._chk(self.lib.pic_set_stream(self._h, C.c_void_p(int(hip_stream)) if hip_stream else None))
+
+    def modes_device(self, max_mode, re_ptr, im_ptr):
+        self._chk(self.lib.pic_get_modes(self._h, int(max_mode), _ptr(int(re_ptr)), _ptr(int(im_ptr)), PIC_DEVICE))
 
     def modes(self, max_mode):
         re = np.empty((self.num_envs, int(max_mode)))

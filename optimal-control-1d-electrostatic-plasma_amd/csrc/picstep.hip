@@ -864,7 +864,8 @@ struct pic_handle {
   size_t sweep_lds = 0, solve_lds = 0;
   double dx = 0, scale = 0;
   double cs[4]{}, ds[4]{};
-  hipStream_t stream = nullptr;
+  hipStream_t stream = nullptr;       // the stream every call works on (own_stream, or the caller's)
+  hipStream_t own_stream = nullptr;   // created by pic_create, destroyed by pic_destroy
   // Cache-resident schedule: pic_step walks the environments in groups whose particles fit the
   // Infinity Cache, each group running all its sweeps back to back on one of `wstreams`.
   std::vector<hipStream_t> wstreams;
@@ -891,6 +892,7 @@ struct pic_handle {
   double* act = nullptr;          // [env][2M] actions
   double* modes = nullptr;        // [2][env][M] Fourier modes (re, im)
   int act_modes = 0;
+  int modes_cap = 0;
   double* aux_n = nullptr;        // eval_field outputs
   double* aux_E = nullptr;
   double* aux_pe = nullptr;
@@ -1163,7 +1165,8 @@ int pic_create(const pic_config* cfg, pic_handle** out) {
   if (h->solve_lds > 64 * 1024)
     CREATE_CHK(hipFuncSetAttribute((const void*)field_solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)h->solve_lds));
-  CREATE_CHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+  CREATE_CHK(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
+  h->stream = h->own_stream;
   {
     // hipGraph replay of a step (PICSTEP_GRAPH=1).  Off by default: at N = 1e4 the 7 dependent kernels cost
     // ~7 us each on the device whichever way they are launched (50.4 us/step eager, 53.9 us/step replayed).
@@ -1248,8 +1251,20 @@ int pic_destroy(pic_handle* h) {
   for (hipStream_t st : h->wstreams) hipStreamDestroy(st);
   for (hipEvent_t ev : h->join_ev) hipEventDestroy(ev);
   if (h->fork_ev) hipEventDestroy(h->fork_ev);
-  if (h->stream) hipStreamDestroy(h->stream);
+  if (h->own_stream) hipStreamDestroy(h->own_stream);
   delete h;
+  return PIC_OK;
+}
+
+int pic_set_stream(pic_handle* h, void* hip_stream) {
+  if (!h) return PIC_EINVAL;
+  HIPCHK(h, hipSetDevice(h->cfg.device_id));
+  HIPCHK(h, hipStreamSynchronize(h->stream));      // drain the old stream: later work must see its results
+  prof_drain(h);
+  for (StepGraph& g : h->graphs)                    // captured on the old stream's behalf; cheap to rebuild
+    if (g.exec) hipGraphExecDestroy(g.exec);
+  h->graphs.clear();
+  h->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : h->own_stream;
   return PIC_OK;
 }
 
@@ -1582,9 +1597,12 @@ int pic_get_modes(pic_handle* h, int max_mode, double* re, double* im, int mem_k
   if (!h->has_state) return fail(h, PIC_ESTATE, "pic_get_modes: call pic_reset first");
   HIPCHK(h, hipSetDevice(h->cfg.device_id));
   const size_t nb = (size_t)h->cfg.num_envs * max_mode * sizeof(double);
-  HIPCHK(h, hipStreamSynchronize(h->stream));
-  if (h->modes) { hipFree(h->modes); h->modes = nullptr; }
-  HIPCHK(h, hipMalloc((void**)&h->modes, 2 * nb));
+  if (max_mode > h->modes_cap) {          // (re)allocate only when a larger mode count is asked for
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (h->modes) { hipFree(h->modes); h->modes = nullptr; }
+    HIPCHK(h, hipMalloc((void**)&h->modes, 2 * nb));
+    h->modes_cap = max_mode;
+  }
   double* dre = h->modes;
   double* dim_ = h->modes + (size_t)h->cfg.num_envs * max_mode;
   hipLaunchKernelGGL(modes_kernel, dim3(max_mode, h->cfg.num_envs), dim3(BLOCK), 0, h->stream, h->E_mesh, dre, dim_,
@@ -1593,7 +1611,7 @@ int pic_get_modes(pic_handle* h, int max_mode, double* re, double* im, int mem_k
   const hipMemcpyKind k = mem_kind == PIC_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
   if (re) HIPCHK(h, hipMemcpyAsync(re, dre, nb, k, h->stream));
   if (im) HIPCHK(h, hipMemcpyAsync(im, dim_, nb, k, h->stream));
-  HIPCHK(h, hipStreamSynchronize(h->stream));
+  if (mem_kind == PIC_HOST) HIPCHK(h, hipStreamSynchronize(h->stream));   // device outputs stay stream-ordered
   return PIC_OK;
 }
 

@@ -102,6 +102,53 @@ class BatchedPIC:
         ek = self.modes(max_mode)
         return np.concatenate([-ek.real, ek.imag], axis=1)
 
+    # -- stream-ordered operation next to torch (no host synchronisation in the loop) ------------------
+    def use_torch_stream(self, stream=None):
+        """Run this environment's kernels on torch's current (or the given) stream, so that torch ops
+        on that stream and environment steps are ordered by the stream alone."""
+        import torch
+        st = torch.cuda.current_stream(self.device) if stream is None else stream
+        self._h.set_stream(st.cuda_stream)
+        self._torch_stream = st
+
+    def use_own_stream(self):
+        self._h.set_stream(None)
+        self._torch_stream = None
+
+    def step_actions_torch(self, actions, nsteps: int = 1):
+        """actions: float64 CUDA tensor [num_envs, 2*max_mode] on this device; consumed in stream order."""
+        if not (actions.is_cuda and actions.dtype.is_floating_point and actions.element_size() == 8
+                and actions.is_contiguous() and tuple(actions.shape) == (self.num_envs, 2 * self.max_mode)):
+            raise ValueError("actions must be a contiguous float64 CUDA tensor [num_envs, 2*max_mode]")
+        shared = getattr(self, "_torch_stream", None) is not None
+        if not shared:      # different streams: order them through the host
+            import torch
+            torch.cuda.current_stream(self.device).synchronize()
+        self._h.step_actions_device(actions.data_ptr(), nsteps)
+        if not shared:
+            self._h.sync()
+
+    def feedback_actions_torch(self, max_mode: int):
+        """`feedback_actions` with everything on the device: returns a float64 CUDA tensor [num_envs, 2*max_mode]."""
+        import torch
+        dev = f"cuda:{self.device}"
+        re = torch.empty((self.num_envs, max_mode), dtype=torch.float64, device=dev)
+        im = torch.empty_like(re)
+        shared = getattr(self, "_torch_stream", None) is not None
+        if not shared:
+            torch.cuda.current_stream(self.device).synchronize()
+        self._h.modes_device(max_mode, re.data_ptr(), im.data_ptr())
+        if not shared:
+            self._h.sync()
+        return torch.cat([-re, im], dim=1)
+
+    def rewards_torch(self):
+        """max(1 - PE_reward, 0) per environment as a CUDA tensor (reward.py:72), read from the zero-copy view."""
+        import torch
+        if not hasattr(self, "_views"):
+            self._views = self.torch_views()
+        return torch.clamp(1.0 - self._views["PE_reward"], min=0.0)
+
     def phase_density(self, nbins: int, vmin: float = -25.0, vmax: float = 25.0):
         """estimate_f (src/control/objective.py:8-14) for every environment, [num_envs, nbins, nbins]:
         the histogram is counted on the device, the normalisation n0/dx/dv/N applied here."""

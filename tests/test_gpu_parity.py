@@ -426,6 +426,41 @@ def test_feedback_control_loop_on_device():
     assert effort.max() < 1.25                         # inside the trainers' action range (|a| <= 1.25)
 
 
+def test_stream_ordered_torch_loop_matches_host_loop(oc, po):
+    """The environment on torch's stream: modes -> action (torch ops) -> step, 30 iterations with no host
+    synchronisation inside the loop, must reproduce the host-synchronous loop."""
+    import torch
+    E_, N, Ng, L, M = 3, 20000, 128, 50.0, 4
+    xs, vs = zip(*[po.synthetic_two_stream(N, L, seed=90 + e) for e in range(E_)])
+    x0, v0 = np.stack(xs), np.stack(vs)
+    act = oc.E_field(L, Ng, M)
+    host = oc.BatchedPIC(E_, N, Ng, L=L, dt=0.1)
+    dev = oc.BatchedPIC(E_, N, Ng, L=L, dt=0.1)
+    for env in (host, dev):
+        env.set_actuator(act)
+        env.reset(x0, v0)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):                       # a non-default torch stream, shared with the library
+        dev.use_torch_stream()
+        gain = torch.full((1, 2 * M), 0.8, dtype=torch.float64, device="cuda:0")
+        total = torch.zeros(E_, dtype=torch.float64, device="cuda:0")
+        for _ in range(30):
+            a = dev.feedback_actions_torch(M) * gain    # torch kernels and library kernels interleave on `side`
+            dev.step_actions_torch(a)
+            total += dev.rewards_torch()
+        side.synchronize()
+    ret = np.zeros(E_)
+    for _ in range(30):
+        host.step_actions(host.feedback_actions(M) * 0.8)
+        ret += host.rewards()
+    (xh, vh), (xd, vd) = host.particles(), dev.particles()
+    assert circ_err(xh, xd, L) / L < 1e-11 and rel_err(vd, vh) < 1e-10
+    assert np.allclose(total.cpu().numpy(), ret, rtol=1e-10)
+    dev.use_own_stream()
+    dev.step()                                          # still usable on its own stream afterwards
+    dev.sync()
+
+
 def test_phase_histogram_and_kl_on_device(oc):
     """estimate_f / compute_kl_divergence with the histogram counted on the device; the
     golden states include values on interior edges, on both outer edges and outside the range."""
