@@ -521,6 +521,61 @@ def test_many_small_envs(oc, po):
     assert env.bad_count() == 0
 
 
+def test_create_destroy_does_not_leak(oc, po):
+    import torch
+    N, Ng, L = 200_000, 256, 50.0
+    x0, v0 = po.synthetic_bump_on_tail(N, L, seed=1)
+
+    def cycle():
+        env = oc.BatchedPIC(4, N, Ng, L=L, dt=0.1)
+        env.set_actuator(oc.E_field(L, Ng, 3))
+        env.reset(np.stack([x0] * 4), np.stack([v0] * 4))
+        env.step_actions(np.zeros((4, 6)), 2)
+        env.modes(3)
+        env.eval_field(np.stack([x0] * 4))
+        env.close()
+
+    cycle()
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    for _ in range(25):
+        cycle()
+    torch.cuda.synchronize()
+    free1 = torch.cuda.mem_get_info()[0]
+    assert free0 - free1 < 64 << 20, (free0, free1)      # 25 cycles of ~40 MB each would show up as ~1 GB
+
+
+def test_two_handles_from_two_threads(oc, po):
+    """Different handles are independent (own stream, own buffers); ctypes drops the GIL during calls."""
+    import threading
+    N, Ng, L = 50_000, 128, 50.0
+    inputs = [po.synthetic_two_stream(N, L, seed=200 + k) for k in range(2)]
+    out = [None, None]
+
+    def work(k):
+        env = oc.BatchedPIC(2, N, Ng, L=L, dt=0.05)
+        x, v = inputs[k]
+        env.reset(np.stack([x, x]), np.stack([v, v]))
+        for _ in range(40):
+            env.step()
+        out[k] = env.particles()
+        env.close()
+
+    ts = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    for k in range(2):
+        env = oc.BatchedPIC(2, N, Ng, L=L, dt=0.05)
+        x, v = inputs[k]
+        env.reset(np.stack([x, x]), np.stack([v, v]))
+        env.step(None, 40)
+        xs, vs = env.particles()
+        assert circ_err(out[k][0], xs, L) / L < 1e-10 and rel_err(out[k][1], vs) < 1e-9
+        env.close()
+
+
 def test_errors_cross_the_abi_as_codes(oc):
     h = oc._abi.Handle(1000, 64, 1, 50.0, 1.0, 0.1)
     with pytest.raises(oc._abi.PicError, match="pic_reset first"):
