@@ -69,6 +69,7 @@ struct SweepArgs {
   int env0;           // first environment of this launch (launches may cover a group of environments)
   double L, dx, rdx, dt;   // rdx = 1/dx (for float particles: 1/(float)dx)
   double c_prev, c_cur, d_cur, c_next;
+  double scale, n0;   // density scale n0 L / N / dx and mean density, for the in-prologue field solve
 };
 
 struct SolveArgs {
@@ -212,6 +213,96 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;
 }
 
+__device__ __forceinline__ double wave_incl_scan(double v) {
+  const int lane = threadIdx.x & 63;
+  for (int off = 1; off < 64; off <<= 1) {
+    double t = __shfl_up(v, off);
+    if (lane >= off) v += t;
+  }
+  return v;
+}
+
+// exclusive prefix of `v` over a workgroup of NW waves (ws: NW doubles of LDS); total in `total`
+template <int NW>
+__device__ __forceinline__ double block_excl_scan(double v, double* ws, double& total) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  double inc = wave_incl_scan(v);
+  if (lane == 63) ws[w] = inc;
+  __syncthreads();
+  double off = 0.0, tot = 0.0;
+  for (int i = 0; i < NW; ++i) {
+    double s = ws[i];
+    if (i < w) off += s;
+    tot += s;
+  }
+  __syncthreads();
+  total = tot;
+  return off + (inc - v);
+}
+
+template <int NW>
+__device__ __forceinline__ double block_sum(double v, double* ws) {
+  double w = wave_sum(v);
+  if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = w;
+  __syncthreads();
+  double s = 0.0;
+  for (int i = 0; i < NW; ++i) s += ws[i];
+  __syncthreads();
+  return s;
+}
+
+// Field tile for a sweep workgroup, computed in its own prologue (256 threads) from the slab the previous
+// sweep wrote: density -> G = dx cumsum(n - n0) - mean -> E_j = -(G_{j+1/2} + G_{j-1/2})/2 (+ E_ext), the same
+// scan solve as field_solve_kernel.  Every workgroup of an environment repeats it (the rows come from L2);
+// in exchange a step needs no field-solve launch between sweeps.  sb: Ng doubles of LDS scratch.
+template <typename T, int OFF>
+__device__ __forceinline__ void prologue_field(const double* __restrict__ slab, int nblk, const double* __restrict__ ext,
+                                               int Ng, double scale, double n0, double dx, double* __restrict__ sb,
+                                               double* __restrict__ ws, T* __restrict__ Es) {
+  const int tid = threadIdx.x;
+  for (int j = tid; j < Ng; j += BLOCK) {
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0, s4 = 0.0, s5 = 0.0, s6 = 0.0, s7 = 0.0;
+    int b = 0;
+    for (; b + 7 < nblk; b += 8) {          // 8 independent loads in flight per lane
+      s0 += slab[(size_t)b * Ng + j];
+      s1 += slab[(size_t)(b + 1) * Ng + j];
+      s2 += slab[(size_t)(b + 2) * Ng + j];
+      s3 += slab[(size_t)(b + 3) * Ng + j];
+      s4 += slab[(size_t)(b + 4) * Ng + j];
+      s5 += slab[(size_t)(b + 5) * Ng + j];
+      s6 += slab[(size_t)(b + 6) * Ng + j];
+      s7 += slab[(size_t)(b + 7) * Ng + j];
+    }
+    for (; b < nblk; ++b) s0 += slab[(size_t)b * Ng + j];
+    sb[j] = (((s0 + s1) + (s2 + s3)) + ((s4 + s5) + (s6 + s7))) * scale - n0;
+  }
+  __syncthreads();
+  const int m = (Ng + BLOCK - 1) / BLOCK;
+  const int lo = min(tid * m, Ng), hi = min(lo + m, Ng);
+  double loc = 0.0;
+  for (int j = lo; j < hi; ++j) loc += sb[j];
+  double tot;
+  double run = block_excl_scan<WAVES>(loc, ws, tot);
+  loc = 0.0;
+  for (int j = lo; j < hi; ++j) {
+    run += sb[j];
+    const double g = run * dx;
+    sb[j] = g;
+    loc += g;
+  }
+  const double gmean = block_sum<WAVES>(loc, ws) / (double)Ng;     // syncs: sb holds G everywhere
+  for (int i = tid; i < Ng + 2; i += BLOCK) {
+    int node = i - OFF;
+    node = node < 0 ? node + Ng : (node >= Ng ? node - Ng : node);
+    const double gp = sb[node] - gmean;
+    const double gm = sb[node == 0 ? Ng - 1 : node - 1] - gmean;
+    double E = -0.5 * (gp + gm);
+    if (ext) E += ext[node];
+    Es[i] = (T)E;
+  }
+  __syncthreads();
+}
+
 // One particle through one sub-stage.  Stages D / REFRESH also deposit the NEXT step's first drift
 // position q1 = x' + (c1 p) dt into a second mesh (acc2), which is exactly what sweep A of the next
 // step would deposit from the stored x', p -- so that sweep (a full read of x and v) is skipped.
@@ -283,6 +374,8 @@ __device__ __forceinline__ void flush_mesh(const A* __restrict__ acc_all, int R,
 template <typename T, typename A, int SHAPE, int STAGE>
 __global__ __launch_bounds__(BLOCK) void sweep_kernel(T* __restrict__ x, T* __restrict__ v,
                                                       const double* __restrict__ Ef,
+                                                      const double* __restrict__ slab_in,
+                                                      const double* __restrict__ ext_in,
                                                       double* __restrict__ part, double* __restrict__ part2,
                                                       double* __restrict__ ke_part,
                                                       unsigned long long* __restrict__ bad_count, SweepArgs a) {
@@ -319,17 +412,26 @@ __global__ __launch_bounds__(BLOCK) void sweep_kernel(T* __restrict__ x, T* __re
 #else
   constexpr bool kPrologue = true;
 #endif
-  if (kPrologue) for (int i = tid; i < nacc; i += BLOCK) acc_all[i] = A(0);
+  // the mesh region doubles as scratch of the in-prologue field solve, so it is zeroed after that solve
+  const bool solve_here = kGather && slab_in != nullptr;
+  if (kPrologue && !solve_here) for (int i = tid; i < nacc; i += BLOCK) acc_all[i] = A(0);
 #ifdef PIC_EXP_STAMPB
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   const unsigned long long sbz = wall_clock64();
 #endif
   if (kGather && kPrologue) {
-    const double* Ee = Ef + (size_t)env * Ng;
-    for (int i = tid; i < stride; i += BLOCK) {
-      int node = i - OFF;
-      node = node < 0 ? node + Ng : (node >= Ng ? node - Ng : node);
-      Es[i] = (T)Ee[node];
+    if (slab_in) {
+      // no field-solve launch ran before this sweep: solve here, with the (not yet zeroed) mesh region as scratch
+      prologue_field<T, OFF>(slab_in + (size_t)env * a.nblk * Ng, a.nblk, ext_in ? ext_in + (size_t)env * Ng : nullptr,
+                             Ng, a.scale, a.n0, a.dx, reinterpret_cast<double*>(smem_raw), red, Es);
+      for (int i = tid; i < nacc; i += BLOCK) acc_all[i] = A(0);
+    } else {
+      const double* Ee = Ef + (size_t)env * Ng;
+      for (int i = tid; i < stride; i += BLOCK) {
+        int node = i - OFF;
+        node = node < 0 ? node + Ng : (node >= Ng ? node - Ng : node);
+        Es[i] = (T)Ee[node];
+      }
     }
   }
 #ifdef PIC_EXP_STAMPB
@@ -574,41 +676,6 @@ constexpr int SBLOCK = 1024;         // field-solve workgroup: 16 waves
 constexpr int SWAVES = SBLOCK / 64;
 constexpr int SGROUPS = 4;           // slab rows are summed by 4 groups of 256 lanes
 
-__device__ __forceinline__ double wave_incl_scan(double v) {
-  const int lane = threadIdx.x & 63;
-  for (int off = 1; off < 64; off <<= 1) {
-    double t = __shfl_up(v, off);
-    if (lane >= off) v += t;
-  }
-  return v;
-}
-
-__device__ __forceinline__ double block_excl_scan(double v, double* ws, double& total) {
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  double inc = wave_incl_scan(v);
-  if (lane == 63) ws[w] = inc;
-  __syncthreads();
-  double off = 0.0, tot = 0.0;
-  for (int i = 0; i < SWAVES; ++i) {
-    double s = ws[i];
-    if (i < w) off += s;
-    tot += s;
-  }
-  __syncthreads();
-  total = tot;
-  return off + (inc - v);
-}
-
-__device__ __forceinline__ double block_sum(double v, double* ws) {
-  double w = wave_sum(v);
-  if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = w;
-  __syncthreads();
-  double s = 0.0;
-  for (int i = 0; i < SWAVES; ++i) s += ws[i];
-  __syncthreads();
-  return s;
-}
-
 __global__ __launch_bounds__(SBLOCK) void field_solve_kernel(
     const double* __restrict__ part, const double* __restrict__ E_ext, const double* __restrict__ ke_part,
     double* __restrict__ n_out, double* __restrict__ Ef_out, double* __restrict__ E_out,
@@ -655,7 +722,7 @@ __global__ __launch_bounds__(SBLOCK) void field_solve_kernel(
   double loc = 0.0;
   for (int j = lo; j < hi; ++j) loc += sb[j];
   double tot;
-  double run = block_excl_scan(loc, ws, tot);
+  double run = block_excl_scan<SWAVES>(loc, ws, tot);
   loc = 0.0;
   for (int j = lo; j < hi; ++j) {
     run += sb[j];
@@ -663,7 +730,7 @@ __global__ __launch_bounds__(SBLOCK) void field_solve_kernel(
     sb[j] = gj;
     loc += gj;
   }
-  const double gmean = block_sum(loc, ws) / (double)Ng;   // syncs: all of sb is G now
+  const double gmean = block_sum<SWAVES>(loc, ws) / (double)Ng;   // syncs: all of sb is G now
 
   // E_j = -(G_{j+1/2} + G_{j-1/2}) / 2, plus the external field for force evaluations (util.py:102-103)
   double e2 = 0.0;
@@ -677,7 +744,7 @@ __global__ __launch_bounds__(SBLOCK) void field_solve_kernel(
     if (E_out) E_out[(size_t)env * Ng + j] = Et;
     e2 += Et * Et;
   }
-  const double S = block_sum(e2, ws);
+  const double S = block_sum<SWAVES>(e2, ws);
   if (tid == 0) {
     double pe = 0.5 * S * a.dx;                       // objective.py:33 / util.py:129
     if (PEr_out) PEr_out[env] = pe;
@@ -687,7 +754,7 @@ __global__ __launch_bounds__(SBLOCK) void field_solve_kernel(
   if (KE_out) {
     double k = 0.0;
     for (int b = tid; b < a.nblk; b += SBLOCK) k += ke_part[(size_t)env * a.nblk + b];
-    k = block_sum(k, ws);
+    k = block_sum<SWAVES>(k, ws);
     if (tid == 0) KE_out[env] = 0.5 * k;              // util.py:144
   }
 
@@ -695,14 +762,14 @@ __global__ __launch_bounds__(SBLOCK) void field_solve_kernel(
     // phi_{j+1} = phi_j + dx G_{j+1/2}: exclusive scan, then remove the mean
     loc = 0.0;
     for (int j = lo; j < hi; ++j) loc += (sb[j] - gmean) * a.dx;
-    run = block_excl_scan(loc, ws, tot);
+    run = block_excl_scan<SWAVES>(loc, ws, tot);
     double ploc = 0.0;
     for (int j = lo; j < hi; ++j) {
       se[j] = run;
       ploc += run;
       run += (sb[j] - gmean) * a.dx;
     }
-    const double pmean = block_sum(ploc, ws) / (double)Ng;
+    const double pmean = block_sum<SWAVES>(ploc, ws) / (double)Ng;
     for (int j = tid; j < Ng; j += SBLOCK) phi_out[(size_t)env * Ng + j] = se[j] - pmean;
   }
 }
@@ -878,6 +945,8 @@ struct pic_handle {
   void* scratch = nullptr;        // [env][ld] staging (eval_field positions, dense<->padded copies)
   double* part = nullptr;         // [env][nblk][Ng] deposit of the sweep just run
   double* part2 = nullptr;        // [env][nblk][Ng] deposit of the NEXT step's q1 (sweeps D / REFRESH)
+  double* part_b = nullptr;       // second buffer for `part` (sweep C writes it while late C workgroups still read `part`)
+  bool fused_solve = false;       // force-evaluation solves in the sweep prologues (4 launches per step)
   int sweep_parity = 0;           // direction of the next push sweep
   bool use_graph = false;         // replay steps from hipGraphs (launch-bound sizes)
   std::vector<StepGraph> graphs;
@@ -941,6 +1010,14 @@ void yoshida_coefficients(double (&c)[4], double (&d)[4]) {
   d[2] = w0;
 }
 
+// what a sweep reads its field from and where its deposits go
+struct SweepIO {
+  const double* slab_in = nullptr;   // non-null: solve the field in the prologue from this slab (+ ext)
+  const double* ext = nullptr;
+  double* out = nullptr;             // slab receiving this sweep's deposit
+  double* out2 = nullptr;            // slab receiving the next step's q1 deposit (dual stages)
+};
+
 // where a launch goes: stream + the block of environments it covers
 struct Lane {
   hipStream_t stream;
@@ -949,28 +1026,29 @@ struct Lane {
 };
 
 template <typename T, typename A, int SHAPE, int STAGE>
-void launch_sweep_t(pic_handle* h, const Lane& ln, void* x, void* v, const SweepArgs& a) {
+void launch_sweep_t(pic_handle* h, const Lane& ln, const SweepIO& io, void* x, void* v, const SweepArgs& a) {
   dim3 grid(h->nblk, ln.nenv);
   hipLaunchKernelGGL((sweep_kernel<T, A, SHAPE, STAGE>), grid, dim3(BLOCK), h->sweep_lds, ln.stream,
-                     static_cast<T*>(x), static_cast<T*>(v), h->Ef, h->part, h->part2, h->ke_part, h->bad, a);
+                     static_cast<T*>(x), static_cast<T*>(v), h->Ef, io.slab_in, io.ext, io.out ? io.out : h->part,
+                     io.out2 ? io.out2 : h->part2, h->ke_part, h->bad, a);
 }
 
 template <typename T, typename A, int SHAPE>
-void launch_sweep_s(pic_handle* h, const Lane& ln, int stage, void* x, void* v, const SweepArgs& a) {
+void launch_sweep_s(pic_handle* h, const Lane& ln, const SweepIO& io, int stage, void* x, void* v, const SweepArgs& a) {
   switch (stage) {
-    case ST_A: launch_sweep_t<T, A, SHAPE, ST_A>(h, ln, x, v, a); break;
-    case ST_B: launch_sweep_t<T, A, SHAPE, ST_B>(h, ln, x, v, a); break;
-    case ST_C: launch_sweep_t<T, A, SHAPE, ST_C>(h, ln, x, v, a); break;
-    case ST_D: launch_sweep_t<T, A, SHAPE, ST_D>(h, ln, x, v, a); break;
-    case ST_REFRESH: launch_sweep_t<T, A, SHAPE, ST_REFRESH>(h, ln, x, v, a); break;
-    default: launch_sweep_t<T, A, SHAPE, ST_PROBE>(h, ln, x, v, a); break;
+    case ST_A: launch_sweep_t<T, A, SHAPE, ST_A>(h, ln, io, x, v, a); break;
+    case ST_B: launch_sweep_t<T, A, SHAPE, ST_B>(h, ln, io, x, v, a); break;
+    case ST_C: launch_sweep_t<T, A, SHAPE, ST_C>(h, ln, io, x, v, a); break;
+    case ST_D: launch_sweep_t<T, A, SHAPE, ST_D>(h, ln, io, x, v, a); break;
+    case ST_REFRESH: launch_sweep_t<T, A, SHAPE, ST_REFRESH>(h, ln, io, x, v, a); break;
+    default: launch_sweep_t<T, A, SHAPE, ST_PROBE>(h, ln, io, x, v, a); break;
   }
 }
 
 template <typename T, typename A>
-void launch_sweep_i(pic_handle* h, const Lane& ln, int stage, void* x, void* v, const SweepArgs& a) {
-  if (h->cfg.interpol == PIC_TSC) launch_sweep_s<T, A, PIC_TSC>(h, ln, stage, x, v, a);
-  else launch_sweep_s<T, A, PIC_CIC>(h, ln, stage, x, v, a);
+void launch_sweep_i(pic_handle* h, const Lane& ln, const SweepIO& io, int stage, void* x, void* v, const SweepArgs& a) {
+  if (h->cfg.interpol == PIC_TSC) launch_sweep_s<T, A, PIC_TSC>(h, ln, io, stage, x, v, a);
+  else launch_sweep_s<T, A, PIC_CIC>(h, ln, io, stage, x, v, a);
 }
 
 // Per-launch HIP-event brackets on the handle's stream.  Events come from a pool that is only grown
@@ -1008,10 +1086,13 @@ void prof_end(pic_handle* h, hipStream_t st) {
 
 Lane whole(pic_handle* h) { return Lane{h->stream, 0, h->cfg.num_envs, 0}; }
 
-void launch_sweep(pic_handle* h, Lane& ln, int stage, void* x, void* v, double c_prev, double c_cur, double d_cur) {
+void launch_sweep(pic_handle* h, Lane& ln, int stage, void* x, void* v, double c_prev, double c_cur, double d_cur,
+                  const SweepIO& io = SweepIO()) {
   SweepArgs a;
   a.c_next = h->cs[0];
   a.env0 = ln.env0;
+  a.scale = h->scale;
+  a.n0 = h->cfg.n0;
   a.N = h->cfg.N; a.ld = h->ld; a.chunk = h->chunk; a.Ng = h->cfg.Ng; a.nblk = h->nblk; a.R = h->R;
 #ifdef PIC_EXP_NOREVERSE
   a.reverse = 0;
@@ -1022,9 +1103,9 @@ void launch_sweep(pic_handle* h, Lane& ln, int stage, void* x, void* v, double c
   a.rdx = h->cfg.particle_dtype == PIC_F64 ? 1.0 / h->dx : (double)(1.0f / (float)h->dx);
   a.c_prev = c_prev; a.c_cur = c_cur; a.d_cur = d_cur;
   prof_begin(h, ln.stream, stage <= ST_D ? stage : 5);
-  if (h->cfg.particle_dtype == PIC_F64) launch_sweep_i<double, double>(h, ln, stage, x, v, a);
-  else if (h->cfg.accum_dtype == PIC_F64) launch_sweep_i<float, double>(h, ln, stage, x, v, a);
-  else launch_sweep_i<float, float>(h, ln, stage, x, v, a);
+  if (h->cfg.particle_dtype == PIC_F64) launch_sweep_i<double, double>(h, ln, io, stage, x, v, a);
+  else if (h->cfg.accum_dtype == PIC_F64) launch_sweep_i<float, double>(h, ln, io, stage, x, v, a);
+  else launch_sweep_i<float, float>(h, ln, io, stage, x, v, a);
   prof_end(h, ln.stream);
 }
 
@@ -1126,7 +1207,13 @@ int pic_create(const pic_config* cfg, pic_handle** out) {
   if (nblk <= 0) {
     const long long target_total = 4096;
     nblk = (target_total + cfg->num_envs - 1) / cfg->num_envs;
-    const long long max_by_work = (cfg->N + 8 * tile - 1) / (8 * tile);   // >= 8 tiles per workgroup
+    // Large problems: >= 8 tiles per workgroup (amortises the prologue and the slab row).  Small, launch-bound
+    // problems (profiles/smalln_bpe.py: N = 1e4 41 -> 30 us/step, N = 5e3 36 -> 28 us/step): one tile per
+    // workgroup, at most 64 workgroups per environment so that the fused prologue solve stays cheap.
+    const bool small = (double)cfg->N * cfg->num_envs <= 4.0e6;
+    const long long tiles_min = small ? 1 : 8;
+    long long max_by_work = (cfg->N + tiles_min * tile - 1) / (tiles_min * tile);
+    if (small && max_by_work > 64) max_by_work = 64;
     if (nblk > max_by_work) nblk = max_by_work;
     if (nblk < 1) nblk = 1;
   }
@@ -1207,6 +1294,14 @@ int pic_create(const pic_config* cfg, pic_handle** out) {
   CREATE_CHK(hipMemsetAsync(h->v, 0, pbytes, h->stream));
   CREATE_CHK(hipMalloc((void**)&h->part, gbytes * h->nblk));
   CREATE_CHK(hipMalloc((void**)&h->part2, gbytes * h->nblk));
+  CREATE_CHK(hipMalloc((void**)&h->part_b, gbytes * h->nblk));
+  {
+    // Every sweep workgroup re-sums its environment's nblk slab rows, so this pays where a step is
+    // launch-bound (config 1: 50.0 -> 40.7 us/step) and is neutral once the sweeps are HBM-bound (config 2:
+    // 1.229 vs 1.224 ms/step): on by default for small problems only.  PICSTEP_FUSED_SOLVE=0/1 overrides.
+    const char* fs = getenv("PICSTEP_FUSED_SOLVE");
+    h->fused_solve = fs ? atoi(fs) != 0 : (h->nblk <= 64 && (double)cfg->N * cfg->num_envs <= 4.0e6);
+  }
   CREATE_CHK(hipMalloc((void**)&h->ke_part, (size_t)cfg->num_envs * h->nblk * sizeof(double)));
   CREATE_CHK(hipMemsetAsync(h->ke_part, 0, (size_t)cfg->num_envs * h->nblk * sizeof(double), h->stream));
   double** grids[] = {&h->Ef, &h->n, &h->E_mesh, &h->phi, &h->ext, &h->aux_n, &h->aux_E};
@@ -1241,7 +1336,7 @@ int pic_destroy(pic_handle* h) {
   if (h->basis) hipFree(h->basis);
   if (h->act) hipFree(h->act);
   if (h->modes) hipFree(h->modes);
-  void* bufs[] = {h->x, h->v, h->scratch, h->part, h->part2, h->ke_part, h->Ef, h->n, h->E_mesh, h->phi, h->ext,
+  void* bufs[] = {h->x, h->v, h->scratch, h->part, h->part2, h->part_b, h->ke_part, h->Ef, h->n, h->E_mesh, h->phi, h->ext,
                   h->aux_n, h->aux_E, h->aux_pe, h->KE, h->bad};
   for (void* b : bufs)
     if (b) hipFree(b);
@@ -1322,6 +1417,26 @@ int pic_step(pic_handle* h, const double* E_ext, int mem_kind, int nsteps) {
   const double* d = h->ds;
   const bool q1_ready = h->q1_ready;
   auto one_step = [&](Lane& ln, bool have_q1) {
+    if (h->fused_solve) {
+      // 4 launches: the three force-evaluation solves run in the prologue of the sweep that needs the field.
+      // Slabs are double-buffered: a workgroup that starts late must still find the rows of the PREVIOUS sweep.
+      SweepIO io;
+      if (!have_q1) {
+        io.out = h->part2;                       // sweep A deposits q1 where sweep D normally leaves it
+        launch_sweep(h, ln, ST_A, h->x, h->v, 0.0, c[0], 0.0, io);
+      }
+      io = SweepIO(); io.slab_in = h->part2; io.ext = ext; io.out = h->part;
+      launch_sweep(h, ln, ST_B, h->x, h->v, c[0], c[1], d[1], io);
+      io = SweepIO(); io.slab_in = h->part; io.ext = ext; io.out = h->part_b;
+      launch_sweep(h, ln, ST_C, h->x, h->v, 0.0, c[2], d[2], io);
+      io = SweepIO(); io.slab_in = h->part_b; io.ext = ext; io.out = h->part; io.out2 = h->part2;
+      launch_sweep(h, ln, ST_D, h->x, h->v, 0.0, c[3], d[3], io);
+      SolveOut o;           // post-step refresh: no external field (pic.py:114-117)
+      o.ke_part = h->ke_part; o.n = h->n; o.E = h->E_mesh; o.phi = h->phi;
+      o.KE = h->KE; o.PE = h->PE; o.PEr = h->PEr;
+      launch_solve(h, ln, o);
+      return;
+    }
     SolveOut f;           // force evaluation: only the gather field is needed
     f.ext = ext; f.Ef = h->Ef;
     if (have_q1) {        // the previous sweep D / reset already deposited q1 = x + (c1 v) dt
