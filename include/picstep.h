@@ -70,6 +70,16 @@ int pic_destroy(pic_handle* h);
  * x0, v0: [num_envs][N] of the particle dtype, host or device. */
 int pic_reset(pic_handle* h, const void* x0, const void* v0, int mem_kind);
 
+/* PIC.reinit with the sample drawn ON THE DEVICE: the distributions of src/env/dist.py (kind 0 =
+ * TwoStream :27-102, halves at +v0 / -v0 with spread sigma; kind 1 = BumpOnTail :104-194, int(N/(1+a))
+ * bulk particles from N(0,1) followed by the beam from N(v0, sigma) -- the index order high_indx relies
+ * on), x uniform on [0, L), v truncated to [-10, 10], then the velocity perturbation
+ * v *= 1 + A sin(2 pi n_mode x / L) (pic.py:68) and update_density + update_E_field.  Counter-based
+ * Philox generator keyed by (seed, environment): reproducible, but NOT the reference's NumPy stream --
+ * the host samplers of the Python layer keep that. */
+int pic_reset_sampled(pic_handle* h, int kind, double a, double v0, double sigma, double A, int n_mode,
+                      uint64_t seed);
+
 /* nsteps x PIC.update_state(E_external) (pic.py:131-146): Yoshida-4 push
  * (src/env/integration.py:60-75), final wrap, density/field refresh, KE/PE reductions.
  * E_ext: NULL or [num_envs][Ng] float64 (held constant over the nsteps), host or device.

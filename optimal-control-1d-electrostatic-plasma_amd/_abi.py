@@ -39,6 +39,7 @@ SIGNATURES = {
     "pic_create": [C.POINTER(PicConfig), C.POINTER(_vp)],
     "pic_destroy": [_vp],
     "pic_reset": [_vp, _vp, _vp, C.c_int],
+    "pic_reset_sampled": [_vp, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int, C.c_uint64],
     "pic_step": [_vp, _vp, C.c_int, C.c_int],
     "pic_get_particles": [_vp, _vp, _vp, C.c_int],
     "pic_set_particles": [_vp, _vp, _vp, C.c_int],
@@ -160,6 +161,11 @@ class Handle:
 
     def reset_device(self, x_ptr, v_ptr):
         self._chk(self.lib.pic_reset(self._h, _ptr(int(x_ptr)), _ptr(int(v_ptr)), PIC_DEVICE))
+
+    def reset_sampled(self, kind, a=0.2, v0=3.0, sigma=1.0, A=0.1, n_mode=2, seed=0):
+        k = {"two-stream": 0, "bump-on-tail": 1}[kind]
+        self._chk(self.lib.pic_reset_sampled(self._h, k, float(a), float(v0), float(sigma), float(A), int(n_mode),
+                                             int(seed) & 0xFFFFFFFFFFFFFFFF))
 
     def set_particles(self, x, v):
         x, v = self._particles_in(x), self._particles_in(v)

@@ -860,6 +860,62 @@ __global__ __launch_bounds__(BLOCK) void modes_kernel(const double* __restrict__
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Device-side initial conditions (the distributions of src/env/dist.py:27-194, not its RNG stream).
+// Philox4x32-10 counter-based generator: particle i of environment e draws from counter (i, attempt)
+// under key (seed, e), so a sample is reproducible and independent of the launch geometry.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void philox4x32_10(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+  for (int r = 0; r < 10; ++r) {
+    const uint32_t hi0 = __umulhi(0xD2511F53u, c[0]), lo0 = 0xD2511F53u * c[0];
+    const uint32_t hi1 = __umulhi(0xCD9E8D57u, c[2]), lo1 = 0xCD9E8D57u * c[2];
+    const uint32_t n0 = hi1 ^ c[1] ^ k0, n2 = hi0 ^ c[3] ^ k1;
+    c[0] = n0; c[1] = lo1; c[2] = n2; c[3] = lo0;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+}
+
+__device__ __forceinline__ double u01(uint32_t a, uint32_t b) {       // 53 random bits -> (0, 1)
+  const unsigned long long bits = ((unsigned long long)a << 21) ^ ((unsigned long long)b >> 11);
+  return ((double)bits + 0.5) * (1.0 / 9007199254740992.0);
+}
+
+// kind 0: two-stream, halves at +v0 / -v0 (dist.py:70-102); kind 1: bump-on-tail, int(N/(1+a)) bulk
+// particles from N(0,1) then the beam from N(v0, sigma) (dist.py:151-189, same ordering as high_indx).
+// Velocities are truncated to [-10, 10] like the reference's uniform proposal; then v *= 1 + A sin(2 pi
+// n_mode x / L) (src/env/pic.py:68).
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void sample_kernel(T* __restrict__ x, T* __restrict__ v, long long N, long long ld,
+                                                       int kind, double a, double v0, double sigma, double A,
+                                                       int n_mode, double L, unsigned long long seed) {
+  const int env = blockIdx.y;
+  const long long n_first = kind == 0 ? N / 2 : (long long)((double)N * (1.0 / (1.0 + a)));
+  for (long long i = (long long)blockIdx.x * BLOCK + threadIdx.x; i < N; i += (long long)gridDim.x * BLOCK) {
+    double mu, sg;
+    if (kind == 0) { mu = i < n_first ? v0 : -v0; sg = sigma; }
+    else { mu = i < n_first ? 0.0 : v0; sg = i < n_first ? 1.0 : sigma; }
+    const uint32_t k0 = (uint32_t)seed ^ (0x85EBCA6Bu * (uint32_t)(env + 1)), k1 = (uint32_t)(seed >> 32);
+    uint32_t c[4] = {(uint32_t)i, (uint32_t)((unsigned long long)i >> 32), 0u, 0x50494331u};
+    philox4x32_10(c, k0, k1);
+    double xs = u01(c[0], c[1]) * L;
+    if (xs >= L) xs = 0.0;
+    double ua = u01(c[2], c[3]), vs = 0.0;
+    for (uint32_t attempt = 1; attempt < 64; ++attempt) {
+      uint32_t d[4] = {(uint32_t)i, (uint32_t)((unsigned long long)i >> 32), attempt, 0x50494332u};
+      philox4x32_10(d, k0, k1);
+      double sn, cs;
+      sincospi(2.0 * u01(d[0], d[1]), &sn, &cs);
+      vs = mu + sg * sqrt(-2.0 * log(ua)) * cs;
+      if (vs >= -10.0 && vs <= 10.0) break;
+      ua = u01(d[2], d[3]);                        // rejected (outside the proposal's support): redraw
+    }
+    vs *= 1.0 + A * sin(2.0 * 3.14159265358979323846 * n_mode * xs / L);
+    x[(size_t)env * ld + i] = (T)xs;
+    v[(size_t)env * ld + i] = (T)vs;
+  }
+}
+
 // np.histogram2d bin of `val` for edges = np.linspace(lo, hi, nb + 1) (edges[i] = lo + i*step, last = hi):
 // searchsorted(edges, val, 'right') - 1, the last edge inclusive, -1 for values outside [lo, hi].
 __device__ __forceinline__ int hist_bin(double val, double lo, double hi, double step, int nb) {
@@ -1728,6 +1784,27 @@ int pic_get_modes(pic_handle* h, int max_mode, double* re, double* im, int mem_k
   if (im) HIPCHK(h, hipMemcpyAsync(im, dim_, nb, k, h->stream));
   if (mem_kind == PIC_HOST) HIPCHK(h, hipStreamSynchronize(h->stream));   // device outputs stay stream-ordered
   return PIC_OK;
+}
+
+int pic_reset_sampled(pic_handle* h, int kind, double a, double v0, double sigma, double A, int n_mode,
+                      uint64_t seed) {
+  if (!h || (kind != 0 && kind != 1) || !(sigma > 0) || (kind == 1 && !(a >= 0)))
+    return fail(h, PIC_EINVAL, "pic_reset_sampled: kind must be 0 (two-stream) or 1 (bump-on-tail), sigma > 0, a >= 0");
+  HIPCHK(h, hipSetDevice(h->cfg.device_id));
+  long long gx = (h->cfg.N + BLOCK - 1) / BLOCK;
+  if (gx > 2048) gx = 2048;
+  dim3 grid((unsigned)gx, h->cfg.num_envs);
+  if (h->cfg.particle_dtype == PIC_F64)
+    hipLaunchKernelGGL(sample_kernel<double>, grid, dim3(BLOCK), 0, h->stream, (double*)h->x, (double*)h->v, h->cfg.N,
+                       h->ld, kind, a, v0, sigma, A, n_mode, h->cfg.L, (unsigned long long)seed);
+  else
+    hipLaunchKernelGGL(sample_kernel<float>, grid, dim3(BLOCK), 0, h->stream, (float*)h->x, (float*)h->v, h->cfg.N,
+                       h->ld, kind, a, v0, sigma, A, n_mode, h->cfg.L, (unsigned long long)seed);
+  HIPCHK(h, hipGetLastError());
+  HIPCHK(h, hipMemsetAsync(h->bad, 0, sizeof(unsigned long long), h->stream));
+  h->has_state = true;
+  h->q1_ready = false;
+  return refresh_fields(h);
 }
 
 int pic_phase_histogram(pic_handle* h, int nbins, double vmin, double vmax, uint32_t* counts) {

@@ -40,6 +40,14 @@ class BatchedPIC:
     def reset(self, x0, v0):
         self._h.reset(x0, v0)
 
+    def reset_sampled(self, kind: str = "bump-on-tail", a: float = 0.2, v0: float = 3.0, sigma: float = 1.0,
+                      A: float = 0.1, n_mode: int = 2, seed: int = 0):
+        """`reinit()` for every environment with the sample drawn on the device: the distributions of the
+        reference's TwoStream / BumpOnTail (same particle ordering), velocity perturbation included.  A new
+        `seed` gives a new ensemble; environment e always differs from environment e'.  Not NumPy's RNG
+        stream -- use `reset(x0, v0)` with the host samplers when the reference's exact particles are wanted."""
+        self._h.reset_sampled(kind, a, v0, sigma, A, n_mode, seed)
+
     def reset_device(self, x_ptr, v_ptr):
         self._h.reset_device(x_ptr, v_ptr)
 

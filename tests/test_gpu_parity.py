@@ -521,6 +521,46 @@ def test_many_small_envs(oc, po):
     assert env.bad_count() == 0
 
 
+def test_device_sampler_matches_reference_distributions(oc):
+    """pic_reset_sampled draws the reference's TwoStream / BumpOnTail distributions on the device.  It is a
+    different RNG, so the check is statistical: two-sample Kolmogorov-Smirnov against the host samplers
+    (which reproduce the reference's stream, golden g10), moments, ordering, reproducibility."""
+    from scipy import stats
+    N, Ng, L = 200_000, 128, 50.0
+    env = oc.BatchedPIC(3, N, Ng, L=L, dt=0.1)
+    np.random.seed(123)
+    for kind, host in (("bump-on-tail", oc.BumpOnTail(a=0.2, v0=3.0, sigma=1.0, n_samples=N, L=L)),
+                       ("two-stream", oc.TwoStream(v0=3.0, sigma=1.0, n_samples=N, L=L))):
+        env.reset_sampled(kind, a=0.2, v0=3.0, sigma=1.0, A=0.0, n_mode=2, seed=7)       # A = 0: raw sample
+        x, v = env.particles()
+        xh, vh = host.get_sample()
+        assert (x >= 0).all() and (x < L).all() and (np.abs(v) <= 10).all() and env.bad_count() == 0
+        n1 = int(N * (1 / 1.2)) if kind == "bump-on-tail" else N // 2
+        for sl in (slice(0, n1), slice(n1, N)):                                          # per population
+            assert stats.ks_2samp(v[0][sl], vh[sl]).pvalue > 1e-3, kind
+        assert stats.ks_2samp(x[0], xh).pvalue > 1e-3
+        assert stats.kstest(x[1] / L, "uniform").pvalue > 1e-3
+        if kind == "bump-on-tail":
+            assert abs(v[0][:n1].mean()) < 0.02 and abs(v[0][n1:].mean() - 3.0) < 0.03
+            assert abs(v[0][:n1].std() - 1.0) < 0.02
+        else:
+            assert abs(v[0][:n1].mean() - 3.0) < 0.02 and abs(v[0][n1:].mean() + 3.0) < 0.02
+        assert not np.array_equal(x[0], x[1]) and abs(np.corrcoef(x[0], x[1])[0, 1]) < 0.02   # envs differ
+        env.reset_sampled(kind, a=0.2, v0=3.0, sigma=1.0, A=0.0, n_mode=2, seed=7)
+        x2, v2 = env.particles()
+        assert np.array_equal(x, x2) and np.array_equal(v, v2)                           # same seed, same sample
+        env.reset_sampled(kind, a=0.2, v0=3.0, sigma=1.0, A=0.1, n_mode=2, seed=7)       # perturbation (pic.py:68)
+        x3, v3 = env.particles()
+        assert np.array_equal(x3, x) and np.allclose(v3, v * (1 + 0.1 * np.sin(2 * np.pi * 2 * x / L)), rtol=1e-13)
+        env.reset_sampled(kind, a=0.2, v0=3.0, sigma=1.0, A=0.1, n_mode=2, seed=8)
+        assert not np.array_equal(env.particles()[0], x)
+    # the sampled state is a valid starting point: fields are there and stepping conserves energy
+    ke0, pe0, _ = env.energies()
+    env.step(None, 20)
+    ke, pe, _ = env.energies()
+    assert np.max(np.abs((ke + pe) / (ke0 + pe0) - 1)) < 1e-3 and env.bad_count() == 0
+
+
 def test_create_destroy_does_not_leak(oc, po):
     import torch
     N, Ng, L = 200_000, 256, 50.0
