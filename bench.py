@@ -16,6 +16,10 @@ import os
 import sys
 import time
 
+# the CPU baseline is a one-thread-per-environment figure: keep BLAS / OpenMP from fanning out
+for _v in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
+    os.environ.setdefault(_v, "1")
+
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -50,11 +54,12 @@ def pmc_traffic(kernel, args, E, N, Ng):
     return json.load(open(path)).get("kernels", {}).get(kernel, {}).get("hbm_bytes_per_launch")
 
 
-def cpu_baseline(N, Ng, L, dt, budget_s=20.0):
-    """The NumPy oracle with the reference's call structure (7 compute_E + refresh per step, dense
-    Ng x Ng operators, np.bincount), one thread, on a bounded sample of the same workload."""
+def _cpu_env(args):
+    """One environment of the CPU baseline: (steps done, seconds) for the faithful NumPy oracle."""
+    N, Ng, L, dt, budget_s, seed = args
+    os.environ.setdefault("OMP_NUM_THREADS", "1")
     from oracle import pic_oracle as po
-    x0, v0 = po.synthetic_bump_on_tail(N, L, seed=1234)
+    x0, v0 = po.synthetic_bump_on_tail(N, L, seed=seed)
     sim = po.OraclePIC(x0, v0, Ng, L=L, dt=dt, perturb=False, faithful=True)
     t0 = time.perf_counter()
     sim.update_state(None)
@@ -63,10 +68,27 @@ def cpu_baseline(N, Ng, L, dt, budget_s=20.0):
     t0 = time.perf_counter()
     for _ in range(steps):
         sim.update_state(None)
-    el = time.perf_counter() - t0
-    return {"value": N * steps / el, "unit": "particle-steps/s", "cores": 1, "kind": "port",
-            "sample": f"1 env of N={N}, Ng={Ng}, {steps} steps of the NumPy oracle (faithful call structure), "
-                      f"{el / steps * 1e3:.0f} ms/step"}
+    return steps, time.perf_counter() - t0
+
+
+def cpu_baseline(N, Ng, L, dt, budget_s=20.0, procs=1):
+    """The NumPy oracle with the reference's call structure (7 compute_E + refresh per step, dense
+    Ng x Ng operators, np.bincount) on a bounded sample of the same workload: one thread (how the
+    reference runs), or `procs` independent environments on `procs` processes (--cpu-procs)."""
+    if procs <= 1:
+        steps, el = _cpu_env((N, Ng, L, dt, budget_s, 1234))
+        return {"value": N * steps / el, "unit": "particle-steps/s", "cores": 1, "kind": "port",
+                "sample": f"1 env of N={N}, Ng={Ng}, {steps} steps of the NumPy oracle (faithful call structure), "
+                          f"{el / steps * 1e3:.0f} ms/step"}
+    import multiprocessing as mp
+    with mp.get_context("spawn").Pool(procs) as pool:
+        t0 = time.perf_counter()
+        res = pool.map(_cpu_env, [(N, Ng, L, dt, budget_s, 1234 + p) for p in range(procs)])
+        wall = time.perf_counter() - t0
+    rate = sum(N * s / e for s, e in res)
+    return {"value": rate, "unit": "particle-steps/s", "cores": procs, "kind": "port",
+            "sample": f"{procs} processes x 1 env of N={N}, Ng={Ng}, {res[0][0]} steps each of the NumPy oracle "
+                      f"(faithful call structure), sum of per-process rates, {wall:.0f} s wall incl. start-up"}
 
 
 def main():
@@ -81,18 +103,26 @@ def main():
     ap.add_argument("--accum", default=None, choices=[None, "float64", "float32"])
     ap.add_argument("--blocks-per-env", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-procs", type=int, default=1, help="processes (one env each) for the CPU baseline")
     ap.add_argument("--profile-steps", type=int, default=-1, help="steps of the event-bracketed pass (-1 = --steps)")
     args = ap.parse_args()
-
-    import torch
-    import ocplasma_amd
-    from ocplasma_amd.env.batched import BatchedPIC
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+
+    # CPU baseline first: with --cpu-procs > 1 it starts worker processes, which must happen before this
+    # process initialises the GPU (no exec from a GPU-initialised process on this pool).
+    cpu_leg = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu_leg = cpu_baseline(args.particles, args.mesh, 50.0, 0.1, procs=args.cpu_procs)
+
+    import torch
+    import ocplasma_amd
+    from ocplasma_amd.env.batched import BatchedPIC
+
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the PIC step has no CPU path")
     # BENCH_BACKEND=gloo + BENCH_SAME_DEVICE=1: rehearsal of the N>1 path on a one-GPU box (every rank
@@ -194,10 +224,7 @@ def main():
         "roofline": roof, "kernels": kernels,
     }
     if rank == 0:
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(N, Ng, L, 0.1)
-        else:
-            out["cpu_baseline"] = None
+        out["cpu_baseline"] = cpu_leg          # measured before the GPU was touched (rank 0, N = 1 only)
         print(json.dumps(out), flush=True)
     env.close()
     if dist is not None:
