@@ -85,13 +85,13 @@ def run_batched(tag, kind, E, N, Ng, dtype, accum, steps, actions_modes=0):
     env.close()
 
 
-def run_config1(steps=500):
+def run_config1(steps=2000):
     np.random.seed(42)
     sim = PIC(N=10000, N_mesh=128, n0=1.0, L=L, dt=0.1, tmin=0.0, tmax=50.0, gamma=5.0, A=0.1, n_mode=2,
               interpol="CIC", init_dist=BumpOnTail(a=0.2, v0=3.0, sigma=1.0, n_samples=10000, L=L))
-    for _ in range(20):
+    for _ in range(1000):                          # the first few hundred steps run ~1.4x slower (clock ramp)
         sim.update_state(None)
-    sim.get_energy()
+        sim.get_energy()
     t0 = time.perf_counter()
     for _ in range(steps):                         # run_wo_oc.py:108-125 without plots / KL
         sim.update_state(None)
