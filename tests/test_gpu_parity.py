@@ -411,6 +411,24 @@ def test_device_actuator_and_feedback_modes(oc, po):
     assert rel_err(Ek[1:M + 1, 0], ek[0]) < 1e-10
 
 
+def test_run_wo_oc_shaped_driver():
+    """The reference's baseline driver flow (run_wo_oc.py) end to end on the drop-in classes."""
+    import importlib.util
+    import os
+    from conftest import ROOT
+    spec = importlib.util.spec_from_file_location("run_wo_oc_example", os.path.join(ROOT, "examples", "run_wo_oc.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    np.random.seed(42)
+    out = mod.main(["--simcase", "bump-on-tail", "--num_particle", "10000", "--num_mesh", "128", "--t_max", "5"], quiet=True)
+    assert out["snapshot"].shape == (20000, 50) and out["E"].shape == (50,)
+    # same seed and sampler stream as the golden config-1 trajectory -> same energies step by step
+    g = load_golden("g5_bump_on_tail_N10000_Ng128")
+    assert rel_err(out["E"], g["H"][1:51]) < 1e-10 and rel_err(out["PE"], g["PE"][1:51]) < 1e-8
+    assert rel_err(out["J_ee"], g["PE_reward"][1:51]) < 1e-8
+    assert abs(out["J_KL"][0]) < 1.0 and np.isfinite(out["J_KL"]).all()
+
+
 def test_feedback_control_loop_on_device():
     """run_feedback.py-shaped closed loop through modes -> action -> device actuator -> step: the
     controlled two-stream plasma must stay far below the free one's saturated field energy."""
