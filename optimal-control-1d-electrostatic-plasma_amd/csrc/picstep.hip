@@ -676,11 +676,27 @@ constexpr int SBLOCK = 1024;         // field-solve workgroup: 16 waves
 constexpr int SWAVES = SBLOCK / 64;
 constexpr int SGROUPS = 4;           // slab rows are summed by 4 groups of 256 lanes
 
-__global__ __launch_bounds__(SBLOCK) void field_solve_kernel(
-    const double* __restrict__ part, const double* __restrict__ E_ext, const double* __restrict__ ke_part,
-    double* __restrict__ n_out, double* __restrict__ Ef_out, double* __restrict__ E_out,
-    double* __restrict__ phi_out, double* __restrict__ KE_out, double* __restrict__ PE_out,
-    double* __restrict__ PEr_out, SolveArgs a) {
+// inputs / outputs of one field solve; a launch carries up to two independent ones (blockIdx.y), e.g. the
+// post-step refresh of step s and the first force evaluation of step s+1
+struct SolveIO {
+  const double* part;      // slab [env][nblk][Ng] to reduce
+  const double* ext;       // E_ext [env][Ng] or null
+  const double* ke_part;   // [env][nblk] or null
+  double *n, *Ef, *E, *phi, *KE, *PE, *PEr;   // any may be null
+};
+
+__global__ __launch_bounds__(SBLOCK) void field_solve_kernel(SolveIO io0, SolveIO io1, SolveArgs a) {
+  const SolveIO io = blockIdx.y == 0 ? io0 : io1;
+  const double* __restrict__ part = io.part;
+  const double* __restrict__ E_ext = io.ext;
+  const double* __restrict__ ke_part = io.ke_part;
+  double* __restrict__ n_out = io.n;
+  double* __restrict__ Ef_out = io.Ef;
+  double* __restrict__ E_out = io.E;
+  double* __restrict__ phi_out = io.phi;
+  double* __restrict__ KE_out = io.KE;
+  double* __restrict__ PE_out = io.PE;
+  double* __restrict__ PEr_out = io.PEr;
   extern __shared__ __align__(16) unsigned char smem_raw[];
   double* sb = reinterpret_cast<double*>(smem_raw);   // b, then G_{j+1/2}
   double* se = sb + a.Ng;                             // E, then phi
@@ -1003,6 +1019,7 @@ struct pic_handle {
   double* part2 = nullptr;        // [env][nblk][Ng] deposit of the NEXT step's q1 (sweeps D / REFRESH)
   double* part_b = nullptr;       // second buffer for `part` (sweep C writes it while late C workgroups still read `part`)
   bool fused_solve = false;       // force-evaluation solves in the sweep prologues (4 launches per step)
+  bool pair_solves = true;        // multi-step calls: final solve of step s + first force solve of s+1 in one launch
   int sweep_parity = 0;           // direction of the next push sweep
   bool use_graph = false;         // replay steps from hipGraphs (launch-bound sizes)
   std::vector<StepGraph> graphs;
@@ -1173,15 +1190,20 @@ struct SolveOut {
   double* KE = nullptr; double* PE = nullptr; double* PEr = nullptr;
 };
 
-void launch_solve(pic_handle* h, const Lane& ln, const SolveOut& o) {
+SolveIO solve_io(pic_handle* h, const SolveOut& o) {
+  return SolveIO{o.slab ? o.slab : h->part, o.ext, o.ke_part, o.n, o.Ef, o.E, o.phi, o.KE, o.PE, o.PEr};
+}
+
+// one solve, or two independent ones in the same launch (second = nullptr for one)
+void launch_solve(pic_handle* h, const Lane& ln, const SolveOut& o, const SolveOut* second = nullptr) {
   SolveArgs a;
   a.env0 = ln.env0;
   a.N = h->cfg.N; a.Ng = h->cfg.Ng; a.nblk = h->nblk; a.L = h->cfg.L; a.dx = h->dx; a.n0 = h->cfg.n0;
   a.scale = h->scale; a.N_over_L = (double)h->cfg.N / h->cfg.L;
+  const SolveIO io0 = solve_io(h, o);
+  const SolveIO io1 = second ? solve_io(h, *second) : io0;
   prof_begin(h, ln.stream, 4);
-  hipLaunchKernelGGL(field_solve_kernel, dim3(ln.nenv), dim3(SBLOCK), h->solve_lds, ln.stream,
-                     o.slab ? o.slab : h->part, o.ext,
-                     o.ke_part, o.n, o.Ef, o.E, o.phi, o.KE, o.PE, o.PEr, a);
+  hipLaunchKernelGGL(field_solve_kernel, dim3(ln.nenv, second ? 2 : 1), dim3(SBLOCK), h->solve_lds, ln.stream, io0, io1, a);
   prof_end(h, ln.stream);
 }
 
@@ -1355,6 +1377,7 @@ int pic_create(const pic_config* cfg, pic_handle** out) {
     // Every sweep workgroup re-sums its environment's nblk slab rows, so this pays where a step is
     // launch-bound (config 1: 50.0 -> 40.7 us/step) and is neutral once the sweeps are HBM-bound (config 2:
     // 1.229 vs 1.224 ms/step): on by default for small problems only.  PICSTEP_FUSED_SOLVE=0/1 overrides.
+    if (const char* ps = getenv("PICSTEP_PAIR_SOLVES")) h->pair_solves = atoi(ps) != 0;
     const char* fs = getenv("PICSTEP_FUSED_SOLVE");
     h->fused_solve = fs ? atoi(fs) != 0 : (h->nblk <= 64 && (double)cfg->N * cfg->num_envs <= 4.0e6);
   }
@@ -1472,7 +1495,7 @@ int pic_step(pic_handle* h, const double* E_ext, int mem_kind, int nsteps) {
   const double* c = h->cs;
   const double* d = h->ds;
   const bool q1_ready = h->q1_ready;
-  auto one_step = [&](Lane& ln, bool have_q1) {
+  auto one_step = [&](Lane& ln, bool have_q1, bool ef_ready = false, bool pair_next = false) {
     if (h->fused_solve) {
       // 4 launches: the three force-evaluation solves run in the prologue of the sweep that needs the field.
       // Slabs are double-buffered: a workgroup that starts late must still find the rows of the PREVIOUS sweep.
@@ -1495,7 +1518,9 @@ int pic_step(pic_handle* h, const double* E_ext, int mem_kind, int nsteps) {
     }
     SolveOut f;           // force evaluation: only the gather field is needed
     f.ext = ext; f.Ef = h->Ef;
-    if (have_q1) {        // the previous sweep D / reset already deposited q1 = x + (c1 v) dt
+    if (ef_ready) {
+      // the previous step's last launch already solved for this step's first force evaluation
+    } else if (have_q1) {   // the previous sweep D / reset already deposited q1 = x + (c1 v) dt
       SolveOut f1 = f;
       f1.slab = h->part2;
       launch_solve(h, ln, f1);
@@ -1511,7 +1536,13 @@ int pic_step(pic_handle* h, const double* E_ext, int mem_kind, int nsteps) {
     SolveOut o;           // post-step refresh: no external field (pic.py:114-117)
     o.ke_part = h->ke_part; o.n = h->n; o.E = h->E_mesh; o.phi = h->phi;
     o.KE = h->KE; o.PE = h->PE; o.PEr = h->PEr;
-    launch_solve(h, ln, o);
+    if (pair_next) {      // another step follows with the same E_ext: solve its first force field in this launch too
+      SolveOut f1 = f;
+      f1.slab = h->part2;
+      launch_solve(h, ln, o, &f1);
+    } else {
+      launch_solve(h, ln, o);
+    }
   };
 
   const int E = h->cfg.num_envs;
@@ -1521,7 +1552,13 @@ int pic_step(pic_handle* h, const double* E_ext, int mem_kind, int nsteps) {
     ln.parity = h->sweep_parity;
     for (int s = 0; s < nsteps; ++s) {
       const bool have_q1 = s > 0 || q1_ready;
-      if (!h->use_graph || h->prof || !have_q1) {
+      if (!h->use_graph || !have_q1) {
+        // unfused schedule: 7 launches for a lone step, 6 per step inside a multi-step call
+        const bool pairing = !h->fused_solve && h->pair_solves;
+        one_step(ln, have_q1, /*ef_ready=*/pairing && s > 0, /*pair_next=*/pairing && s + 1 < nsteps);
+        continue;
+      }
+      if (h->prof) {
         one_step(ln, have_q1);
         continue;
       }
