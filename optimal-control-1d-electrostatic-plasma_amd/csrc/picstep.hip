@@ -714,16 +714,20 @@ __global__ __launch_bounds__(SBLOCK) void field_solve_kernel(SolveIO io0, SolveI
   const double* slab = part + (size_t)env * a.nblk * Ng;
   const int g = tid >> 8, lane = tid & 255;
   for (int j = lane; j < Ng; j += 256) {
-    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0, s4 = 0.0, s5 = 0.0, s6 = 0.0, s7 = 0.0;
     int b = g;
-    for (; b + 3 * SGROUPS < a.nblk; b += 4 * SGROUPS) {
+    for (; b + 7 * SGROUPS < a.nblk; b += 8 * SGROUPS) {       // 8 independent loads in flight per lane
       s0 += slab[(size_t)b * Ng + j];
       s1 += slab[(size_t)(b + SGROUPS) * Ng + j];
       s2 += slab[(size_t)(b + 2 * SGROUPS) * Ng + j];
       s3 += slab[(size_t)(b + 3 * SGROUPS) * Ng + j];
+      s4 += slab[(size_t)(b + 4 * SGROUPS) * Ng + j];
+      s5 += slab[(size_t)(b + 5 * SGROUPS) * Ng + j];
+      s6 += slab[(size_t)(b + 6 * SGROUPS) * Ng + j];
+      s7 += slab[(size_t)(b + 7 * SGROUPS) * Ng + j];
     }
     for (; b < a.nblk; b += SGROUPS) s0 += slab[(size_t)b * Ng + j];
-    sp[g * Ng + j] = (s0 + s1) + (s2 + s3);
+    sp[g * Ng + j] = ((s0 + s1) + (s2 + s3)) + ((s4 + s5) + (s6 + s7));
   }
   __syncthreads();
   for (int j = tid; j < Ng; j += SBLOCK) {
