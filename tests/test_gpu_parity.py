@@ -579,6 +579,46 @@ def test_device_sampler_matches_reference_distributions(oc):
     assert np.max(np.abs((ke + pe) / (ke0 + pe0) - 1)) < 1e-3 and env.bad_count() == 0
 
 
+def test_pic_api_corners(oc, po):
+    """Less-travelled parts of the drop-in surface: update_params(dt), assigning x / v, float32 state,
+    update_density / update_E_field, and ShardedPIC on a single rank with the real BatchedPIC behind it."""
+    g = load_golden("g4_bump_on_tail_ext_N4000_Ng256")
+    L = float(g["L"])
+    sim = make_pic(oc, g)
+    # update_params(dt=...) re-creates the device handle and carries the particles over
+    x_before = sim.x.copy()
+    sim.update_params(dt=0.05, gamma=None)
+    assert sim.dt == 0.05 and np.array_equal(sim.x, x_before)
+    sim.update_state(None)
+    ref = po.OraclePIC(g["x0_raw"], g["v0_raw"], int(g["Ng"]), L=L, dt=0.05, A=float(g["A"]), n_mode=int(g["n_mode"]),
+                       perturb=True, faithful=False)
+    ref.update_state(None)
+    assert circ_err(sim.x, ref.x, L) / L < 1e-13 and rel_err(sim.v, ref.v) < 1e-13
+    # assigning particles uploads them and refreshes the fields
+    sim.x = ref.x[::-1].copy()
+    sim.v = ref.v[::-1].copy()
+    assert rel_err(sim.E_mesh, ref.E_mesh) < 1e-11 and abs(sim.get_energy() / ref.get_energy() - 1) < 1e-13
+    sim.update_density()
+    sim.update_E_field()
+    assert rel_err(sim.n, ref.n) < 1e-12
+    sim.close()
+    # float32 drop-in: the API still hands out float64 arrays
+    s32 = make_pic(oc, g, dtype="float32")
+    s32.update_state(None)
+    assert s32.x.dtype == np.float64 and s32.get_state().shape == (8000, 1)
+    assert abs(s32.get_energy() / float(g["H"][0]) - 1) < 1e-3
+    s32.close()
+    # one-rank ShardedPIC = plain BatchedPIC
+    sh = oc.env.sharded.ShardedPIC(3, 5000, 64, L=L, dt=0.1)
+    xs, vs = zip(*[po.synthetic_two_stream(5000, L, seed=300 + e) for e in range(3)])
+    sh.reset(np.stack(xs), np.stack(vs), is_global=True)
+    sh.step(None, 3)
+    r = sh.gather_returns()
+    e = sh.gather_energies()
+    assert r.shape == (3,) and e.shape == (3, 3) and (r >= 0).all() and (r <= 1).all()
+    sh.close()
+
+
 def test_create_destroy_does_not_leak(oc, po):
     import torch
     N, Ng, L = 200_000, 256, 50.0
