@@ -46,7 +46,10 @@
 
 namespace {
 
-constexpr int BLOCK = 256;          // 4 waves of 64
+#ifndef PIC_BLOCK
+#define PIC_BLOCK 512               // sweep workgroup size: 512 beats 256 by 2.7 % and 128 by 11 % at config 2
+#endif
+constexpr int BLOCK = PIC_BLOCK;    // 8 waves of 64
 constexpr int WAVES = BLOCK / 64;
 
 enum Stage : int {
@@ -1287,7 +1290,7 @@ int pic_create(const pic_config* cfg, pic_handle** out) {
   const long long tile = (long long)BLOCK * h->vec;
   long long nblk = cfg->blocks_per_env;
   if (nblk <= 0) {
-    const long long target_total = 4096;
+    const long long target_total = 8192;      // ~128 workgroups per env at 64 envs (profiles/experiments_r1.md)
     nblk = (target_total + cfg->num_envs - 1) / cfg->num_envs;
     // Large problems: >= 8 tiles per workgroup (amortises the prologue and the slab row).  Small, launch-bound
     // problems (profiles/smalln_bpe.py: N = 1e4 41 -> 30 us/step, N = 5e3 36 -> 28 us/step): one tile per
@@ -1311,7 +1314,10 @@ int pic_create(const pic_config* cfg, pic_handle** out) {
   h->nblk = (int)nblk;
 
   const size_t stride = (size_t)cfg->Ng + 2;
-  h->R = 4;   // LDS: 2 R meshes (sweep D deposits two) + the field tile
+  // LDS: 2 R meshes (sweep D deposits two) + the field tile; up to 4 mesh copies (waves w and w+4 share
+  // one: 8 copies measured no better) while the workgroup stays within 40 KB, i.e. 4 workgroups per CU
+  h->R = WAVES < 4 ? WAVES : 4;
+  if (const char* mr = getenv("PICSTEP_MAX_R")) { const int m = atoi(mr); while (m >= 1 && h->R > m) h->R >>= 1; }
   while (h->R > 1 && 2 * h->R * stride * h->asz + stride * h->esz > 40 * 1024) h->R >>= 1;
   h->sweep_lds = 2 * h->R * stride * h->asz + stride * h->esz;
   h->solve_lds = (2 + SGROUPS) * (size_t)cfg->Ng * sizeof(double);
