@@ -100,7 +100,7 @@ def main():
     ap.add_argument("--particles", type=int, default=1_000_000)
     ap.add_argument("--mesh", type=int, default=256)
     ap.add_argument("--dtype", default="float64", choices=["float64", "float32"])
-    ap.add_argument("--accum", default=None, choices=[None, "float64", "float32"])
+    ap.add_argument("--accum", default=None, choices=[None, "float64", "float32", "fixed"])
     ap.add_argument("--blocks-per-env", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-procs", type=int, default=1, help="processes (one env each) for the CPU baseline")

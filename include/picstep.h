@@ -28,7 +28,8 @@ extern "C" {
 
 #define PICSTEP_ABI_VERSION 1
 
-enum { PIC_F64 = 0, PIC_F32 = 1 };           /* particle / deposit-accumulator dtype          */
+enum { PIC_F64 = 0, PIC_F32 = 1,             /* particle / deposit-accumulator dtype          */
+       PIC_FIXED = 2 };                       /* accumulator only: packed 64-bit fixed point   */
 enum { PIC_CIC = 0, PIC_TSC = 1 };           /* src/env/interpolate.py:4 (CIC), :22 (TSC)     */
 enum { PIC_HOST = 0, PIC_DEVICE = 1 };       /* where a caller buffer lives                   */
 
@@ -52,7 +53,9 @@ typedef struct pic_config {
   double  dt;              /* time step (post-clamp)                                      */
   double  gamma;           /* unused by the scan solver                                   */
   int32_t particle_dtype;  /* PIC_F64 | PIC_F32                                           */
-  int32_t accum_dtype;     /* deposit accumulator in LDS: PIC_F64 | PIC_F32 (F32 needs F32 particles) */
+  int32_t accum_dtype;     /* deposit accumulator in LDS: PIC_F64 | PIC_F32 | PIC_FIXED (the last two
+                              need F32 particles; PIC_FIXED is CIC only: count + sum of w_r in one
+                              64-bit word, 2^-24 weight resolution, one LDS atomic per deposit)       */
   int32_t interpol;        /* PIC_CIC | PIC_TSC                                           */
   int32_t device_id;       /* HIP device ordinal                                          */
   int32_t blocks_per_env;  /* 0 = choose; workgroups streaming one environment per sweep  */

@@ -10,7 +10,7 @@ import numpy as np
 
 from . import _build
 
-PIC_F64, PIC_F32 = 0, 1
+PIC_F64, PIC_F32, PIC_FIXED = 0, 1, 2
 PIC_CIC, PIC_TSC = 0, 1
 PIC_HOST, PIC_DEVICE = 0, 1
 ABI_VERSION = 1
@@ -120,9 +120,15 @@ class Handle:
                  accum_dtype=None, interpol="CIC", device_id=0, blocks_per_env=0):
         self.lib = load()
         pd = {"float64": PIC_F64, "float32": PIC_F32}[str(np.dtype(particle_dtype))]
-        # LDS mesh accumulator: float64 unless asked otherwise, also for float32 particles -- measured on
-        # MI355X, ds_add_f32 deposition runs ~4x slower than ds_add_f64 (profiles/experiments_r1.md)
-        ad = PIC_F64 if accum_dtype is None else {"float64": PIC_F64, "float32": PIC_F32}[str(np.dtype(accum_dtype))]
+        # LDS mesh accumulator.  float64 particles: float64 (the parity mode).  float32 particles: "fixed" for
+        # CIC (count + sum of w_r packed in one 64-bit word, one integer LDS atomic per deposit), float64 for TSC;
+        # "float32" exists but ds_add_f32 deposits ~4x slower than ds_add_f64 on MI355X (profiles/experiments_r1.md)
+        if accum_dtype is None:
+            ad = PIC_FIXED if (pd == PIC_F32 and interpol == "CIC") else PIC_F64
+        elif str(accum_dtype) == "fixed":
+            ad = PIC_FIXED
+        else:
+            ad = {"float64": PIC_F64, "float32": PIC_F32}[str(np.dtype(accum_dtype))]
         self.cfg = PicConfig(int(N), int(Ng), int(num_envs), float(L), float(n0), float(dt), float(gamma), pd, ad,
                              {"CIC": PIC_CIC, "TSC": PIC_TSC}[interpol], int(device_id), int(blocks_per_env), 0)
         self.N, self.Ng, self.num_envs = int(N), int(Ng), int(num_envs)

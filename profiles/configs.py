@@ -118,11 +118,11 @@ if __name__ == "__main__":
     if 2 in which:
         run_batched("config 2 (bump-on-tail N=1e6 Ng=256 64 envs fp64)", "bump", 64, 1_000_000, 256, "float64", None, 20)
     if 3 in which:
-        run_batched("config 3 (two-stream N=1e6 Ng=512 128 envs fp32 particles / fp64 LDS mesh, random actions every step)",
-                    "two", 128, 1_000_000, 512, "float32", "float64", 20, actions_modes=3)
+        run_batched("config 3 (two-stream N=1e6 Ng=512 128 envs fp32 particles / packed fixed-point LDS mesh, random "
+                    "actions every step)", "two", 128, 1_000_000, 512, "float32", None, 20, actions_modes=3)
     if 4 in which:
         run_batched("config 4 share (bump-on-tail N=4e6 Ng=1024 64 envs fp64)", "bump", 64, 4_000_000, 1024,
                     "float64", None, 10)
     if 5 in which:
-        run_batched("config 5 share (bump-on-tail N=1e7 Ng=256 128 envs, fp32 push / fp64 mesh)", "bump", 128,
-                    10_000_000, 256, "float32", "float64", 5)
+        run_batched("config 5 share (bump-on-tail N=1e7 Ng=256 128 envs, fp32 push / fixed-point deposit / fp64 Poisson)",
+                    "bump", 128, 10_000_000, 256, "float32", None, 5)

@@ -340,15 +340,15 @@ def test_full_size_invariants_and_one_step_parity(oc, po):
 
 
 def test_float32_modes_track_float64(oc, po):
-    """fp32 particles (config 3: fp32 accumulator; config 5: fp64 mesh accumulation). Bounds are
-    measured, not derived: single-precision positions on a 50-long box carry ~3e-6 absolute error."""
+    """fp32 particles with each LDS accumulator (packed fixed point = the default for CIC, fp64, fp32). Bounds
+    are measured, not derived: single-precision positions on a 50-long box carry ~3e-6 absolute error."""
     N, Ng, L = 200_000, 512, 50.0
     x0, v0 = po.synthetic_two_stream(N, L, seed=5)
     ref = oc.BatchedPIC(1, N, Ng, L=L, dt=0.1)
     ref.reset(x0[None], v0[None])
     ref.step(None, 10)
     _, Er, _ = ref.fields()
-    for acc in ("float32", "float64"):
+    for acc in (None, "fixed", "float32", "float64"):
         env = oc.BatchedPIC(1, N, Ng, L=L, dt=0.1, dtype="float32", accum_dtype=acc)
         env.reset(x0[None].astype(np.float32), v0[None].astype(np.float32))
         env.step(None, 10)
@@ -359,6 +359,45 @@ def test_float32_modes_track_float64(oc, po):
         kr, pr, _ = ref.energies()
         assert rel_err(E, Er) < 5e-2, acc
         assert abs(ke[0] / kr[0] - 1) < 1e-5 and abs(pe[0] / pr[0] - 1) < 5e-2
+
+
+def test_fixed_point_accumulator_matches_float64_accumulator(oc, po):
+    """PIC_FIXED deposits (count, sum of w_r) per cell in one integer LDS atomic; the density it yields is
+    the fp64-accumulated one up to the 2^-24 weight quantum and w_l := 1 - w_r, and its total charge is exact."""
+    L = 50.0
+    for N, Ng, E_, bpe in ((200_000, 512, 2, 0), (30_001, 257, 1, 3), (4_000, 64, 3, 1)):
+        rng = np.random.default_rng(N)
+        x0 = rng.uniform(0, L, (E_, N)).astype(np.float32)
+        x0[:, :4] = [0.0, np.nextafter(np.float32(L), np.float32(0)), L / Ng, 3 * L / Ng]
+        v0 = rng.normal(0, 1, (E_, N)).astype(np.float32)
+        dens = {}
+        for acc in ("fixed", "float64"):
+            env = oc.BatchedPIC(E_, N, Ng, L=L, dt=0.05, dtype="float32", accum_dtype=acc, blocks_per_env=bpe)
+            env.reset(x0, v0)
+            n_reset, _, _ = env.fields()
+            env.step(None, 3)
+            n_step, E, _ = env.fields()
+            dens[acc] = (n_reset, n_step, E, env.particles())
+        dx = L / Ng
+        per_particle = 1.0 * L / N / dx                     # density one whole particle adds to a node
+        for k in (0, 1):
+            d = np.abs(dens["fixed"][k] - dens["float64"][k]).max()
+            # float32 w_l + w_r misses 1 by up to ~ulp(x)/dx = 4e-5; measured 1.9e-4 of this unit at Ng = 257
+            assert d < 1e-3 * per_particle * (N / Ng) ** 0.5, (N, k, d)
+        assert np.abs(dens["fixed"][0].sum(axis=1) * dx - L).max() < 1e-12          # integer sums: charge is exact (fp64 accumulation of float32 weights: 6e-7)
+        assert rel_err(dens["fixed"][2], dens["float64"][2]) < 1e-4                 # measured <= 1e-5
+        assert np.abs(dens["fixed"][3][1] - dens["float64"][3][1]).max() < 2e-5     # measured <= 1.5e-6
+
+
+def test_fixed_point_accumulator_needs_float32_cic(oc):
+    from ocplasma_amd._abi import PicError
+    with pytest.raises(PicError, match="float32 particles"):
+        oc.BatchedPIC(1, 1000, 64, dtype="float64", accum_dtype="fixed")
+    with pytest.raises(PicError, match="CIC only"):
+        oc.BatchedPIC(1, 1000, 64, dtype="float32", accum_dtype="fixed", interpol="TSC")
+    env = oc.BatchedPIC(1, 1000, 64, dtype="float32", interpol="TSC")      # default falls back to the fp64 accumulator
+    env.reset(np.zeros((1, 1000), np.float32) + 1.0, np.zeros((1, 1000), np.float32))
+    assert abs(env.fields()[0].sum() * (50.0 / 64) - 50.0) < 1e-5              # float32 TSC weights sum to 1 within 4e-8
 
 
 def test_torch_zero_copy_views(oc, po):

@@ -126,6 +126,12 @@ def test_bad_config_is_rejected(lib_path):
     assert b"N>=1" in lib.pic_last_error(None)
     cfg = _abi.PicConfig(100, 64, 1, 50.0, 1.0, 0.1, 5.0, 0, 1, 0, 0, 0, 0)   # f32 accumulator, f64 particles
     assert lib.pic_create(ctypes.byref(cfg), ctypes.byref(h)) == -1
+    cfg = _abi.PicConfig(100, 64, 1, 50.0, 1.0, 0.1, 5.0, 0, 2, 0, 0, 0, 0)   # fixed-point accumulator, f64 particles
+    assert lib.pic_create(ctypes.byref(cfg), ctypes.byref(h)) == -1
+    assert b"float32 particles" in lib.pic_last_error(None)
+    cfg = _abi.PicConfig(100, 64, 1, 50.0, 1.0, 0.1, 5.0, 1, 2, 1, 0, 0, 0)   # fixed-point accumulator, TSC
+    assert lib.pic_create(ctypes.byref(cfg), ctypes.byref(h)) == -1
+    assert b"CIC only" in lib.pic_last_error(None)
 
 
 def test_product_never_imports_oracle():
