@@ -158,6 +158,11 @@ def main():
         env.sync()
 
     env.step(None, nsteps=args.warmup)
+    if dist is not None:
+        # RCCL sets a collective up on its first use: run the ones of the timed region once, untimed
+        w = torch.as_tensor(env.rewards(), device=cdev)
+        dist.all_gather([torch.empty_like(w) for _ in range(world)], w)
+        dist.all_reduce(torch.zeros(1, device=cdev, dtype=torch.float64), op=dist.ReduceOp.MAX)
     barrier()
     t0 = time.perf_counter()
     env.step(None, nsteps=args.steps)
