@@ -22,7 +22,9 @@ def needs_build():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = [SRC, os.path.join(INCLUDE, "picstep.h"), os.path.abspath(__file__)]
+    csrc = os.path.dirname(SRC)
+    deps = [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".hip", ".h"))]
+    deps += [os.path.join(INCLUDE, "picstep.h"), os.path.abspath(__file__)]
     return any(os.path.getmtime(d) > t for d in deps)
 
 
@@ -41,7 +43,7 @@ def _compile(out, defines=(), verbose=False):
 
 
 def build_library(force=False, verbose=False):
-    """Compile csrc/picstep.hip -> csrc/libpicstep.so. Returns the library path."""
+    """Compile csrc/picstep.hip (+ its pic_*.h kernel headers) -> csrc/libpicstep.so. Returns the library path."""
     if not force and not needs_build():
         return LIB
     return _compile(LIB, (), verbose)

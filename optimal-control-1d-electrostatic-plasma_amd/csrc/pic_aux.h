@@ -1,0 +1,197 @@
+// pic_aux.h -- kernels off the step path: particle-field gather, CIC bookkeeping, actuator, Fourier modes,
+// Philox sampler, phase-space histogram, streaming probe.
+#pragma once
+#include "pic_device.h"
+
+namespace {
+
+// PIC.E (pic.py:120) and the CIC bookkeeping attributes (pic.py:104-107), on demand.
+template <typename T, int SHAPE>
+__global__ __launch_bounds__(BLOCK) void gather_E_kernel(const T* __restrict__ x, const double* __restrict__ E_mesh,
+                                                         T* __restrict__ E_out, long long N, long long ld, int Ng,
+                                                         double Ld, double dxd) {
+  constexpr int OFF = (SHAPE == PIC_TSC) ? 1 : 0;
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  T* Es = reinterpret_cast<T*>(smem_raw);
+  const int env = blockIdx.y;
+  for (int i = threadIdx.x; i < Ng + 2; i += BLOCK) {
+    int node = i - OFF;
+    node = node < 0 ? node + Ng : (node >= Ng ? node - Ng : node);
+    Es[i] = (T)E_mesh[(size_t)env * Ng + node];
+  }
+  __syncthreads();
+  const T L = (T)Ld, dx = (T)dxd;
+  for (long long i = (long long)blockIdx.x * BLOCK + threadIdx.x; i < N; i += (long long)gridDim.x * BLOCK) {
+    T w[3], xw;
+    int j;
+    unsigned bad = 0;
+    locate<T, SHAPE>(x[(size_t)env * ld + i], L, dx, T(1) / dx, Ng, xw, j, w, bad);
+    E_out[(size_t)env * N + i] = gather_field<T, SHAPE>(Es, j, w);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void cic_query_kernel(const T* __restrict__ x, long long N, int Ng, double Ld,
+                                                          double dxd, long long* __restrict__ jl,
+                                                          long long* __restrict__ jr, double* __restrict__ wl,
+                                                          double* __restrict__ wr) {
+  const T L = (T)Ld, dx = (T)dxd;
+  for (long long i = (long long)blockIdx.x * BLOCK + threadIdx.x; i < N; i += (long long)gridDim.x * BLOCK) {
+    T w[3], xw;
+    int j;
+    unsigned bad = 0;
+    locate<T, PIC_CIC>(x[i], L, dx, T(1) / dx, Ng, xw, j, w, bad);
+    if (jl) jl[i] = j;
+    if (jr) jr[i] = (j + 1 == Ng) ? 0 : j + 1;
+    if (wl) wl[i] = (double)w[0];
+    if (wr) wr[i] = (double)w[1];
+  }
+}
+
+// E_field.compute_E (src/control/actuator.py:54-63) for every environment:
+// E_ext[e][j] = sum_m basis_cos[j][m] a[e][m] + sum_m basis_sin[j][m] a[e][M+m].  The basis tables come from the
+// host mirror (they carry the reference's linspace(0, L, Ng) mesh, actuator.py:13).
+__global__ __launch_bounds__(BLOCK) void actuator_kernel(const double* __restrict__ bc, const double* __restrict__ bs,
+                                                         const double* __restrict__ act, double* __restrict__ ext,
+                                                         int Ng, int M) {
+  const int env = blockIdx.y;
+  const int j = blockIdx.x * BLOCK + threadIdx.x;
+  if (j >= Ng) return;
+  const double* a = act + (size_t)env * 2 * M;
+  double c = 0.0, s = 0.0;
+  for (int m = 0; m < M; ++m) c += bc[(size_t)j * M + m] * a[m];
+  for (int m = 0; m < M; ++m) s += bs[(size_t)j * M + m] * a[M + m];
+  ext[(size_t)env * Ng + j] = c + s;
+}
+
+// compute_E_k_spectrum rows 1..M (src/interpret/spectrum.py:16): Ek[m] = fft(E_mesh)[m] / Ng * 2.
+__global__ __launch_bounds__(BLOCK) void modes_kernel(const double* __restrict__ E_mesh, double* __restrict__ re,
+                                                      double* __restrict__ im, int Ng, int M) {
+  __shared__ double wr[WAVES], wi[WAVES];
+  const int env = blockIdx.y, m = blockIdx.x + 1;
+  double sr = 0.0, si = 0.0;
+  for (int j = threadIdx.x; j < Ng; j += BLOCK) {
+    // angle = 2 pi m j / Ng, reduced exactly in integers before the trig call
+    const long long r = ((long long)m * j) % Ng;
+    double sn, cs;
+    sincospi(2.0 * (double)r / (double)Ng, &sn, &cs);
+    const double e = E_mesh[(size_t)env * Ng + j];
+    sr += e * cs;
+    si -= e * sn;
+  }
+  sr = wave_sum(sr);
+  si = wave_sum(si);
+  if ((threadIdx.x & 63) == 0) { wr[threadIdx.x >> 6] = sr; wi[threadIdx.x >> 6] = si; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double a = 0.0, b = 0.0;
+    for (int w = 0; w < WAVES; ++w) { a += wr[w]; b += wi[w]; }
+    re[(size_t)env * M + (m - 1)] = a / Ng * 2.0;
+    im[(size_t)env * M + (m - 1)] = b / Ng * 2.0;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Device-side initial conditions (the distributions of src/env/dist.py:27-194, not its RNG stream).
+// Philox4x32-10 counter-based generator: particle i of environment e draws from counter (i, attempt)
+// under key (seed, e), so a sample is reproducible and independent of the launch geometry.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void philox4x32_10(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+  for (int r = 0; r < 10; ++r) {
+    const uint32_t hi0 = __umulhi(0xD2511F53u, c[0]), lo0 = 0xD2511F53u * c[0];
+    const uint32_t hi1 = __umulhi(0xCD9E8D57u, c[2]), lo1 = 0xCD9E8D57u * c[2];
+    const uint32_t n0 = hi1 ^ c[1] ^ k0, n2 = hi0 ^ c[3] ^ k1;
+    c[0] = n0; c[1] = lo1; c[2] = n2; c[3] = lo0;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+}
+
+__device__ __forceinline__ double u01(uint32_t a, uint32_t b) {       // 53 random bits -> (0, 1)
+  const unsigned long long bits = ((unsigned long long)a << 21) ^ ((unsigned long long)b >> 11);
+  return ((double)bits + 0.5) * (1.0 / 9007199254740992.0);
+}
+
+// kind 0: two-stream, halves at +v0 / -v0 (dist.py:70-102); kind 1: bump-on-tail, int(N/(1+a)) bulk
+// particles from N(0,1) then the beam from N(v0, sigma) (dist.py:151-189, same ordering as high_indx).
+// Velocities are truncated to [-10, 10] like the reference's uniform proposal; then v *= 1 + A sin(2 pi
+// n_mode x / L) (src/env/pic.py:68).
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void sample_kernel(T* __restrict__ x, T* __restrict__ v, long long N, long long ld,
+                                                       int kind, double a, double v0, double sigma, double A,
+                                                       int n_mode, double L, unsigned long long seed) {
+  const int env = blockIdx.y;
+  const long long n_first = kind == 0 ? N / 2 : (long long)((double)N * (1.0 / (1.0 + a)));
+  for (long long i = (long long)blockIdx.x * BLOCK + threadIdx.x; i < N; i += (long long)gridDim.x * BLOCK) {
+    double mu, sg;
+    if (kind == 0) { mu = i < n_first ? v0 : -v0; sg = sigma; }
+    else { mu = i < n_first ? 0.0 : v0; sg = i < n_first ? 1.0 : sigma; }
+    const uint32_t k0 = (uint32_t)seed ^ (0x85EBCA6Bu * (uint32_t)(env + 1)), k1 = (uint32_t)(seed >> 32);
+    uint32_t c[4] = {(uint32_t)i, (uint32_t)((unsigned long long)i >> 32), 0u, 0x50494331u};
+    philox4x32_10(c, k0, k1);
+    double xs = u01(c[0], c[1]) * L;
+    if (xs >= L) xs = 0.0;
+    double ua = u01(c[2], c[3]), vs = 0.0;
+    for (uint32_t attempt = 1; attempt < 64; ++attempt) {
+      uint32_t d[4] = {(uint32_t)i, (uint32_t)((unsigned long long)i >> 32), attempt, 0x50494332u};
+      philox4x32_10(d, k0, k1);
+      double sn, cs;
+      sincospi(2.0 * u01(d[0], d[1]), &sn, &cs);
+      vs = mu + sg * sqrt(-2.0 * log(ua)) * cs;
+      if (vs >= -10.0 && vs <= 10.0) break;
+      ua = u01(d[2], d[3]);                        // rejected (outside the proposal's support): redraw
+    }
+    vs *= 1.0 + A * sin(2.0 * 3.14159265358979323846 * n_mode * xs / L);
+    x[(size_t)env * ld + i] = (T)xs;
+    v[(size_t)env * ld + i] = (T)vs;
+  }
+}
+
+// np.histogram2d bin of `val` for edges = np.linspace(lo, hi, nb + 1) (edges[i] = lo + i*step, last = hi):
+// searchsorted(edges, val, 'right') - 1, the last edge inclusive, -1 for values outside [lo, hi].
+__device__ __forceinline__ int hist_bin(double val, double lo, double hi, double step, int nb) {
+  if (!(val >= lo && val <= hi)) return -1;
+  int b = (int)((val - lo) / step);
+  b = b < 0 ? 0 : (b > nb - 1 ? nb - 1 : b);
+  auto edge = [&](int i) { return i == nb ? hi : lo + (double)i * step; };
+  while (b > 0 && val < edge(b)) --b;
+  while (b < nb - 1 && val >= edge(b + 1)) ++b;
+  return b;
+}
+
+// Phase-space histogram of the KL diagnostic (src/control/objective.py:8-14): counts[env][ix][iv].
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void phase_hist_kernel(const T* __restrict__ x, const T* __restrict__ v,
+                                                           unsigned* __restrict__ counts, long long N, long long ld,
+                                                           int nb, double L, double vmin, double vmax) {
+  const int env = blockIdx.y;
+  const double sx = (L - 0.0) / nb, sv = (vmax - vmin) / nb;      // np.linspace step = (stop - start) / div
+  unsigned* c = counts + (size_t)env * nb * nb;
+  for (long long i = (long long)blockIdx.x * BLOCK + threadIdx.x; i < N; i += (long long)gridDim.x * BLOCK) {
+    const int ix = hist_bin((double)x[(size_t)env * ld + i], 0.0, L, sx, nb);
+    const int iv = hist_bin((double)v[(size_t)env * ld + i], vmin, vmax, sv, nb);
+    if (ix >= 0 && iv >= 0) atomicAdd(&c[(size_t)ix * nb + iv], 1u);
+  }
+}
+
+// Streaming ceiling of this box for the sweeps' access shape: read two arrays, write two arrays, 16 B
+// per lane, same grid -- what a sweep would take if it did no arithmetic at all.
+__global__ __launch_bounds__(BLOCK) void stream_probe_kernel(double2* __restrict__ a, double2* __restrict__ b,
+                                                             long long n2, long long chunk2, double scale,
+                                                             int reverse, int work) {
+  const long long bid = reverse ? (long long)gridDim.x - 1 - blockIdx.x : blockIdx.x;
+  long long begin = bid * chunk2;
+  long long end = begin + chunk2 < n2 ? begin + chunk2 : n2;
+  for (long long i = begin + threadIdx.x; i < end; i += BLOCK) {
+    double2 u = a[i], w = b[i];
+    u.x *= scale; u.y *= scale; w.x *= scale; w.y *= scale;
+    for (int k = 0; k < work; ++k) {   // experiment: dependent fp64 work between the load and the store
+      u.x = fma(u.x, scale, w.x * 1e-300); w.x = fma(w.x, scale, u.y * 1e-300);
+      u.y = fma(u.y, scale, w.y * 1e-300); w.y = fma(w.y, scale, u.x * 1e-300);
+    }
+    a[i] = u;
+    b[i] = w;
+  }
+}
+
+}  // namespace

@@ -45,980 +45,11 @@
 
 #include "picstep.h"
 
-namespace {
+#include "pic_device.h"
+#include "pic_sweep.h"
+#include "pic_solve.h"
+#include "pic_aux.h"
 
-#ifndef PIC_BLOCK
-#define PIC_BLOCK 512               // sweep workgroup size: 512 beats 256 by 2.7 % and 128 by 11 % at config 2
-#endif
-constexpr int BLOCK = PIC_BLOCK;    // 8 waves of 64
-constexpr int WAVES = BLOCK / 64;
-
-enum Stage : int {
-  ST_A = 0,        // drift(c) from x,v ; deposit ; nothing stored
-  ST_B = 1,        // recompute q1 = x + (c_prev v) dt ; gather ; kick ; drift ; deposit ; store
-  ST_C = 2,        // gather ; kick ; drift ; deposit ; store
-  ST_D = 3,        // as C, then wrap, KE ; store wrapped x
-  ST_REFRESH = 4,  // wrap x ; deposit ; KE ; store wrapped x            (pic.py:93-112 on reset)
-  ST_PROBE = 5     // deposit positions of a scratch array, nothing stored (util.py:73-116 callers)
-};
-
-struct SweepArgs {
-  long long N;        // particles per env
-  long long ld;       // leading dimension of x, v
-  long long chunk;    // particles per workgroup (multiple of BLOCK * VEC)
-  int Ng;
-  int nblk;           // workgroups per env
-  int R;              // LDS mesh replicas per workgroup (1, 2 or 4)
-  int reverse;        // walk environments and chunks from the far end (alternates sweep to sweep)
-  int env0;           // first environment of this launch (launches may cover a group of environments)
-  double L, dx, rdx, dt;   // rdx = 1/dx (for float particles: 1/(float)dx)
-  double c_prev, c_cur, d_cur, c_next;
-  double scale, n0;   // density scale n0 L / N / dx and mean density, for the in-prologue field solve
-};
-
-struct SolveArgs {
-  long long N;
-  int Ng;
-  int nblk;
-  double L, dx, n0;
-  int env0;            // first environment of this launch
-  double scale;        // n0 * L / N / dx, evaluated left to right as interpolate.py:18
-  double N_over_L;
-};
-
-// ---------------------------------------------------------------------------------------------
-// np.mod(np.mod(q, L), L): PIC.update_state wraps once (pic.py:139) and compute_n wraps the same
-// array again in place (util.py:51) before CIC wraps its copy (interpolate.py:6), so a value that
-// the first mod rounds up to exactly L ends as 0.  The three fast ranges are bit-identical to
-// fmod-based np.mod (Sterbenz: q-L is exact for L <= q < 2L).
-// ---------------------------------------------------------------------------------------------
-template <typename T>
-__device__ __noinline__ T wrap_periodic_far(T q, T L) {   // |q| beyond one box length: rare
-  T r = fmod(q, L);
-  if (r < T(0)) {
-    r += L;
-    if (r >= L) r = T(0);
-  } else if (r == T(0)) {
-    r = T(0);   // np.mod returns +0 for a zero remainder
-  }
-  return r;
-}
-
-template <typename T>
-__device__ __forceinline__ T wrap_periodic(T q, T L) {
-#ifdef PIC_EXP_BRANCHY_WRAP
-  T r;
-  if (q >= T(0) && q < L) {
-    r = q;
-  } else if (q >= L && q < L + L) {
-    r = q - L;
-  } else if (q < T(0) && q >= -L) {
-    r = q + L;
-    if (r >= L) r = T(0);
-  } else {
-    r = wrap_periodic_far(q, L);
-  }
-  return r;
-#else
-  // the three near ranges as selects (a particle moves a small fraction of L per sub-stage)
-  T up = q + L;                       // q in [-L, 0)
-  up = (up >= L) ? T(0) : up;         // tiny negative q: q + L rounds to L, the second mod gives 0
-  T r = (q < T(0)) ? up : q;
-  r = (q >= L) ? q - L : r;           // q in [L, 2L): exact (Sterbenz)
-  if (__builtin_expect(!(q >= -L && q < L + L), 0)) r = wrap_periodic_far(q, L);
-  return r;
-#endif
-}
-
-// a / dx for the loop-invariant divisor dx, with rdx = 1/dx rounded once on the host: one Newton
-// correction on the reciprocal product, q0 = a rdx; q = q0 + (a - q0 dx) rdx, both steps fused.
-// The value before the final rounding is within ~2^-104 relative of a/dx, so the result is the
-// IEEE quotient unless a/dx lies that close to a rounding boundary (probability ~2^-52 per
-// operation, then 1 ulp off) -- 3 instructions instead of the ~12 of the full v_div_* sequence,
-// which made sweep D division-bound.  tests/ check it bit for bit against true division.
-template <typename T>
-__device__ __forceinline__ T div_dx(T a, T dx, T rdx) {
-#if defined(PIC_EXP_TRUEDIV)
-  return a / dx;
-#elif defined(PIC_EXP_RCPDIV)
-  return a * rdx;
-#else
-  T q0 = a * rdx;
-  T rem = fma(-q0, dx, a);
-  return fma(rem, rdx, q0);
-#endif
-}
-
-// Cell index and shape-function weights at position q.  j is the LDS index of the leftmost
-// touched node (mesh node + OFF, OFF = 1 for TSC so that node -1 has a slot).
-//   CIC (interpolate.py:6-13): jl = floor(xw/dx); wl = ((jl+1) dx - xw)/dx; wr = (xw - jl dx)/dx
-//   TSC (interpolate.py:24-34): d = (xw - jm dx)/dx; wl = .5(1.5-d)^2; wm = .75-(d-1)^2; wr = .5(d-.5)^2
-template <typename T, int SHAPE>
-__device__ __forceinline__ void locate(T q, T L, T dx, T rdx, int Ng, T& xw, int& j, T (&w)[3], unsigned& bad) {
-  xw = wrap_periodic(q, L);
-  if (!(xw >= T(0) && xw < L)) {   // NaN / inf position: count it, park it on node 0, never index with it
-    bad += 1u;
-    xw = T(0);
-  }
-  T jf = floor(div_dx(xw, dx, rdx));
-  j = (int)jf;
-  // j == Ng happens when xw/dx rounds up to Ng (undefined in the reference: bincount grows a bin and
-  // solve.py:32 raises); it is folded to node 0 with the weights of the unfolded index.
-  if ((unsigned)j >= (unsigned)Ng) j = 0;
-  if (SHAPE == PIC_CIC) {
-    w[0] = div_dx((jf + T(1)) * dx - xw, dx, rdx);
-    w[1] = div_dx(xw - jf * dx, dx, rdx);
-    w[2] = T(0);
-  } else {
-    T d = div_dx(xw - jf * dx, dx, rdx);
-    T a = T(1.5) - d, b = d - T(1), c = d - T(0.5);
-    w[0] = T(0.5) * (a * a);
-    w[1] = T(0.75) - b * b;
-    w[2] = T(0.5) * (c * c);
-  }
-}
-
-template <typename T, int SHAPE>
-__device__ __forceinline__ T gather_field(const T* __restrict__ Es, int j, const T (&w)[3]) {
-  T e = w[0] * Es[j] + w[1] * Es[j + 1];
-  if (SHAPE == PIC_TSC) e = e + w[2] * Es[j + 2];
-  return e;
-}
-
-// Packed fixed-point LDS accumulator for float32 particles (accum_dtype PIC_FIXED, CIC only).  A particle in
-// cell j adds w_l = 1 - w_r to node j and w_r to node j+1, so per cell the pair (count, sum of w_r) carries the
-// whole deposit: n_j = count_j - S_j + S_{j-1}.  Both live in one 64-bit word -- count in the top 20 bits,
-// S in 2^-24 units below -- and one native ds_add_u64 replaces two ds_add_f64 (sweep D of config 3:
-// 0.458 -> 0.395 ms; integer sums are also order-independent).  2^-24 is below the rounding of a float32
-// weight; a workgroup handles fewer than 2^20 particles (pic_create sees to it), so neither field overflows.
-using fix_t = unsigned long long;
-constexpr int FX_FRAC = 24;
-constexpr int FX_LOW = 44;
-
-template <typename A, typename T, int SHAPE>
-__device__ __forceinline__ void deposit(A* __restrict__ acc, int j, const T (&w)[3]) {
-#ifdef PIC_EXP_NODEPOSIT   // timing experiment only: keep the operands alive, drop the LDS atomics
-  asm volatile("" ::"v"(w[0]), "v"(w[1]), "v"(j));
-  (void)acc;
-#else
-  if constexpr (std::is_same<A, fix_t>::value) {
-    // one integer atomic per particle into its own cell: count in the high field, w_r in the low one
-    static_assert(SHAPE == PIC_CIC, "the packed accumulator is CIC only");
-    const float wr = fminf(fmaxf((float)w[1], 0.0f), 1.0f);
-    atomicAdd(&acc[j], (1ull << FX_LOW) + (unsigned long long)(unsigned)(wr * (float)(1u << FX_FRAC) + 0.5f));
-  } else {
-    atomicAdd(&acc[j], (A)w[0]);
-    atomicAdd(&acc[j + 1], (A)w[1]);
-    if (SHAPE == PIC_TSC) atomicAdd(&acc[j + 2], (A)w[2]);
-  }
-#endif
-}
-
-#ifndef PIC_PIPE
-#define PIC_PIPE 0      // tiles prefetched ahead of the one being pushed (experiment; the compiler sinks them)
-#endif
-#ifndef PIC_TILES
-#define PIC_TILES 1     // 16-B tiles per lane per loop iteration
-#endif
-#define PIC_LOAD(p) (*(p))
-#define PIC_STORE(v, p) (*(p) = (v))
-
-template <typename T> struct VecOf;
-typedef double pic_v2d __attribute__((ext_vector_type(2)));   // 16 B per lane either way
-typedef float pic_v4f __attribute__((ext_vector_type(4)));
-template <> struct VecOf<double> { using type = pic_v2d; static constexpr int n = 2; };
-template <> struct VecOf<float> { using type = pic_v4f; static constexpr int n = 4; };
-
-__device__ __forceinline__ double wave_sum(double v) {
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
-  return v;
-}
-
-__device__ __forceinline__ double wave_incl_scan(double v) {
-  const int lane = threadIdx.x & 63;
-  for (int off = 1; off < 64; off <<= 1) {
-    double t = __shfl_up(v, off);
-    if (lane >= off) v += t;
-  }
-  return v;
-}
-
-// exclusive prefix of `v` over a workgroup of NW waves (ws: NW doubles of LDS); total in `total`
-template <int NW>
-__device__ __forceinline__ double block_excl_scan(double v, double* ws, double& total) {
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  double inc = wave_incl_scan(v);
-  if (lane == 63) ws[w] = inc;
-  __syncthreads();
-  double off = 0.0, tot = 0.0;
-  for (int i = 0; i < NW; ++i) {
-    double s = ws[i];
-    if (i < w) off += s;
-    tot += s;
-  }
-  __syncthreads();
-  total = tot;
-  return off + (inc - v);
-}
-
-template <int NW>
-__device__ __forceinline__ double block_sum(double v, double* ws) {
-  double w = wave_sum(v);
-  if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = w;
-  __syncthreads();
-  double s = 0.0;
-  for (int i = 0; i < NW; ++i) s += ws[i];
-  __syncthreads();
-  return s;
-}
-
-// Field tile for a sweep workgroup, computed in its own prologue (256 threads) from the slab the previous
-// sweep wrote: density -> G = dx cumsum(n - n0) - mean -> E_j = -(G_{j+1/2} + G_{j-1/2})/2 (+ E_ext), the same
-// scan solve as field_solve_kernel.  Every workgroup of an environment repeats it (the rows come from L2);
-// in exchange a step needs no field-solve launch between sweeps.  sb: Ng doubles of LDS scratch.
-template <typename T, int OFF>
-__device__ __forceinline__ void prologue_field(const double* __restrict__ slab, int nblk, const double* __restrict__ ext,
-                                               int Ng, double scale, double n0, double dx, double* __restrict__ sb,
-                                               double* __restrict__ ws, T* __restrict__ Es) {
-  const int tid = threadIdx.x;
-  for (int j = tid; j < Ng; j += BLOCK) {
-    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0, s4 = 0.0, s5 = 0.0, s6 = 0.0, s7 = 0.0;
-    int b = 0;
-    for (; b + 7 < nblk; b += 8) {          // 8 independent loads in flight per lane
-      s0 += slab[(size_t)b * Ng + j];
-      s1 += slab[(size_t)(b + 1) * Ng + j];
-      s2 += slab[(size_t)(b + 2) * Ng + j];
-      s3 += slab[(size_t)(b + 3) * Ng + j];
-      s4 += slab[(size_t)(b + 4) * Ng + j];
-      s5 += slab[(size_t)(b + 5) * Ng + j];
-      s6 += slab[(size_t)(b + 6) * Ng + j];
-      s7 += slab[(size_t)(b + 7) * Ng + j];
-    }
-    for (; b < nblk; ++b) s0 += slab[(size_t)b * Ng + j];
-    sb[j] = (((s0 + s1) + (s2 + s3)) + ((s4 + s5) + (s6 + s7))) * scale - n0;
-  }
-  __syncthreads();
-  const int m = (Ng + BLOCK - 1) / BLOCK;
-  const int lo = min(tid * m, Ng), hi = min(lo + m, Ng);
-  double loc = 0.0;
-  for (int j = lo; j < hi; ++j) loc += sb[j];
-  double tot;
-  double run = block_excl_scan<WAVES>(loc, ws, tot);
-  loc = 0.0;
-  for (int j = lo; j < hi; ++j) {
-    run += sb[j];
-    const double g = run * dx;
-    sb[j] = g;
-    loc += g;
-  }
-  const double gmean = block_sum<WAVES>(loc, ws) / (double)Ng;     // syncs: sb holds G everywhere
-  for (int i = tid; i < Ng + 2; i += BLOCK) {
-    int node = i - OFF;
-    node = node < 0 ? node + Ng : (node >= Ng ? node - Ng : node);
-    const double gp = sb[node] - gmean;
-    const double gm = sb[node == 0 ? Ng - 1 : node - 1] - gmean;
-    double E = -0.5 * (gp + gm);
-    if (ext) E += ext[node];
-    Es[i] = (T)E;
-  }
-  __syncthreads();
-}
-
-// One particle through one sub-stage.  Stages D / REFRESH also deposit the NEXT step's first drift
-// position q1 = x' + (c1 p) dt into a second mesh (acc2), which is exactly what sweep A of the next
-// step would deposit from the stored x', p -- so that sweep (a full read of x and v) is skipped.
-template <typename T, typename A, int SHAPE, int STAGE>
-__device__ __forceinline__ void push_one(T& xq, T& vp, const T* __restrict__ Es, A* __restrict__ acc,
-                                         A* __restrict__ acc2, T L, T dx, T rdx, T dt, T c_prev, T c_cur, T d_cur,
-                                         T c_next, int Ng, double& ke, unsigned& bad) {
-#if defined(PIC_EXP_LEVEL) && PIC_EXP_LEVEL <= 1      // timing experiment: stream only (results are wrong)
-  xq = xq + T(0); vp = vp + T(0);
-  return;
-#endif
-  T w[3];
-  T xw;
-  int j;
-  T q = xq, p = vp;
-  if (STAGE == ST_A) {
-    q = q + (c_cur * p) * dt;                                   // integration.py:42, c1
-  } else if (STAGE == ST_B || STAGE == ST_C || STAGE == ST_D) {
-    if (STAGE == ST_B) q = q + (c_prev * p) * dt;               // q1 again (it is never stored)
-    locate<T, SHAPE>(q, L, dx, rdx, Ng, xw, j, w, bad);
-#if defined(PIC_EXP_LEVEL) && PIC_EXP_LEVEL == 2      // timing experiment: arithmetic only, no LDS traffic
-    T E = w[0] * T(0.25) + w[1] * T(0.5) + T(j) * T(1e-30);
-#else
-    T E = gather_field<T, SHAPE>(Es, j, w);                     // util.py:105 / pic.py:120
-#endif
-    p = p + (d_cur * (-E)) * dt;                                // integration.py:32, pic.py:127
-    q = q + (c_cur * p) * dt;                                   // integration.py:42
-  }
-  locate<T, SHAPE>(q, L, dx, rdx, Ng, xw, j, w, bad);
-#if defined(PIC_EXP_LEVEL) && (PIC_EXP_LEVEL == 2 || PIC_EXP_LEVEL == 3)   // no deposit (3: gather kept)
-  asm volatile("" ::"v"(w[0]), "v"(w[1]), "v"(j));
-#else
-  deposit<A, T, SHAPE>(acc, j, w);
-#endif
-  if (STAGE == ST_D || STAGE == ST_REFRESH) {
-    q = xw;                                                     // pic.py:139 (+ util.py:51)
-    ke += (double)p * (double)p;
-    T qn = q + (c_next * p) * dt;                               // next step's q1 (integration.py:42, c1)
-    T xn;
-    locate<T, SHAPE>(qn, L, dx, rdx, Ng, xn, j, w, bad);
-    deposit<A, T, SHAPE>(acc2, j, w);
-  }
-  xq = q;
-  vp = p;
-}
-
-// fold the periodic ghost slots and the replicas of one LDS mesh, store it as this workgroup's slab row
-template <typename A, int SHAPE>
-__device__ __forceinline__ void flush_mesh(const A* __restrict__ acc_all, int R, int stride, int Ng,
-                                           double* __restrict__ row) {
-  constexpr int OFF = (SHAPE == PIC_TSC) ? 1 : 0;
-  if constexpr (std::is_same<A, fix_t>::value) {
-    for (int c = threadIdx.x; c < Ng; c += BLOCK) {
-      const int cm = c == 0 ? Ng - 1 : c - 1;
-      unsigned long long own = 0ull, left = 0ull;
-      for (int r = 0; r < R; ++r) {
-        own += acc_all[(size_t)r * stride + c];
-        left += acc_all[(size_t)r * stride + cm];
-      }
-      const long long mask = (1ll << FX_LOW) - 1;
-      const long long q = ((long long)(own >> FX_LOW) << FX_FRAC) - ((long long)own & mask) + ((long long)left & mask);
-      row[c] = (double)q * (1.0 / (double)(1 << FX_FRAC));      // exact: |q| < 2^45
-    }
-    return;
-  }
-  for (int c = threadIdx.x; c < Ng; c += BLOCK) {
-    double s = 0.0;
-    for (int r = 0; r < R; ++r) {
-      const A* ar = acc_all + (size_t)r * stride;
-      double t = (double)ar[c + OFF];
-      if (SHAPE == PIC_CIC) {
-        if (c == 0) t += (double)ar[Ng];
-      } else {
-        if (c == 0) t += (double)ar[Ng + 1];
-        if (c == Ng - 1) t += (double)ar[0];
-      }
-      s += t;
-    }
-    row[c] = s;
-  }
-}
-
-template <typename T, typename A, int SHAPE, int STAGE>
-__global__ __launch_bounds__(BLOCK) void sweep_kernel(T* __restrict__ x, T* __restrict__ v,
-                                                      const double* __restrict__ Ef,
-                                                      const double* __restrict__ slab_in,
-                                                      const double* __restrict__ ext_in,
-                                                      double* __restrict__ part, double* __restrict__ part2,
-                                                      double* __restrict__ ke_part,
-                                                      unsigned long long* __restrict__ bad_count, SweepArgs a) {
-  constexpr int OFF = (SHAPE == PIC_TSC) ? 1 : 0;
-  constexpr int VEC = VecOf<T>::n;
-  using V = typename VecOf<T>::type;
-  constexpr bool kGather = (STAGE == ST_B || STAGE == ST_C || STAGE == ST_D);
-  constexpr bool kStore = (STAGE == ST_B || STAGE == ST_C || STAGE == ST_D || STAGE == ST_REFRESH);
-  constexpr bool kStoreV = (STAGE == ST_B || STAGE == ST_C || STAGE == ST_D);
-  constexpr bool kReadV = (STAGE != ST_PROBE);
-  constexpr bool kDual = (STAGE == ST_D || STAGE == ST_REFRESH);
-
-  // LDS: [R meshes: acc][R meshes: acc2 (dual stages)][field tile Es]
-  extern __shared__ __align__(16) unsigned char smem_raw[];
-  const int Ng = a.Ng;
-  const int stride = Ng + 2;
-  const int nacc = (kDual ? 2 : 1) * a.R * stride;
-  A* acc_all = reinterpret_cast<A*>(smem_raw);
-  A* acc2_all = acc_all + (size_t)a.R * stride;
-  T* Es = reinterpret_cast<T*>(smem_raw + (size_t)2 * a.R * stride * sizeof(A));
-  __shared__ double red[WAVES];
-
-  const int tid = threadIdx.x;
-  // Consecutive sweeps walk memory in opposite directions: what the previous sweep wrote last (still
-  // in the 256 MB Infinity Cache) is what this one reads first.
-  const int env = a.env0 + (a.reverse ? (int)gridDim.y - 1 - (int)blockIdx.y : (int)blockIdx.y);
-  const int blk = a.reverse ? (int)gridDim.x - 1 - (int)blockIdx.x : (int)blockIdx.x;
-
-#ifdef PIC_EXP_STAMPB
-  const unsigned long long sb0 = wall_clock64();
-#endif
-#if defined(PIC_EXP_LEVEL) && PIC_EXP_LEVEL <= 0
-  constexpr bool kPrologue = false;      // timing experiment: no LDS zeroing / field tile / barrier
-#else
-  constexpr bool kPrologue = true;
-#endif
-  // the mesh region doubles as scratch of the in-prologue field solve, so it is zeroed after that solve
-  const bool solve_here = kGather && slab_in != nullptr;
-  if (kPrologue && !solve_here) for (int i = tid; i < nacc; i += BLOCK) acc_all[i] = A(0);
-#ifdef PIC_EXP_STAMPB
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  const unsigned long long sbz = wall_clock64();
-#endif
-  if (kGather && kPrologue) {
-    if (slab_in) {
-      // no field-solve launch ran before this sweep: solve here, with the (not yet zeroed) mesh region as scratch
-      prologue_field<T, OFF>(slab_in + (size_t)env * a.nblk * Ng, a.nblk, ext_in ? ext_in + (size_t)env * Ng : nullptr,
-                             Ng, a.scale, a.n0, a.dx, reinterpret_cast<double*>(smem_raw), red, Es);
-      for (int i = tid; i < nacc; i += BLOCK) acc_all[i] = A(0);
-    } else {
-      const double* Ee = Ef + (size_t)env * Ng;
-      for (int i = tid; i < stride; i += BLOCK) {
-        int node = i - OFF;
-        node = node < 0 ? node + Ng : (node >= Ng ? node - Ng : node);
-        Es[i] = (T)Ee[node];
-      }
-    }
-  }
-#ifdef PIC_EXP_STAMPB
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-  const unsigned long long sbe = wall_clock64();
-#endif
-  if (kPrologue) __syncthreads();
-
-  const int rep = (tid >> 6) & (a.R - 1);
-  A* acc = acc_all + (size_t)rep * stride;
-  A* acc2 = acc2_all + (size_t)rep * stride;
-  const T L = (T)a.L, dx = (T)a.dx, rdx = (T)a.rdx, dt = (T)a.dt;
-  const T c_prev = (T)a.c_prev, c_cur = (T)a.c_cur, d_cur = (T)a.d_cur, c_next = (T)a.c_next;
-
-  T* xe = x + (size_t)env * a.ld;
-  T* ve = v + (size_t)env * a.ld;
-  const long long step = (long long)BLOCK * VEC;
-
-  double ke = 0.0;
-  unsigned bad = 0u;
-#ifdef PIC_EXP_STAMPB
-  const unsigned long long sb1 = wall_clock64();
-#endif
-  // A workgroup owns the runs blk, blk + nblk, blk + 2 nblk, ... of `chunk` particles of its environment.
-  // chunk = ceil(N / nblk) gives every workgroup one contiguous region; a chunk of a few tiles interleaves
-  // the workgroups of an environment, so that the addresses in flight form a compact moving window.
-  for (long long begin = (long long)blk * a.chunk; begin < a.N; begin += (long long)a.nblk * a.chunk) {
-  long long end = begin + a.chunk;
-  if (end > a.N) end = a.N;
-  long long i = begin + (long long)tid * VEC;
-#if PIC_PIPE == 0
-  // PIC_TILES tiles per lane per iteration: all their loads are issued before the first particle is
-  // pushed, so a wave keeps PIC_TILES x 2 KB of requests in flight while it waits.
-#ifdef PIC_EXP_STAMP   // diagnostic build: wall-clock (10 ns ticks) spent waiting for loads vs pushing, per wave 0
-  unsigned long long st_mem = 0, st_cmp = 0, st_n = 0;
-#endif
-  for (; i + (long long)(PIC_TILES - 1) * step + VEC <= end; i += (long long)PIC_TILES * step) {
-    V xv[PIC_TILES], vv[PIC_TILES];
-#ifdef PIC_EXP_STAMP
-    __builtin_amdgcn_sched_barrier(0);
-    const unsigned long long st0 = wall_clock64();
-    __builtin_amdgcn_sched_barrier(0);
-#endif
-#pragma unroll
-    for (int t = 0; t < PIC_TILES; ++t) {
-      xv[t] = PIC_LOAD(reinterpret_cast<const V*>(xe + i + (long long)t * step));
-      vv[t] = V{};
-      if (kReadV) vv[t] = PIC_LOAD(reinterpret_cast<const V*>(ve + i + (long long)t * step));
-    }
-#ifdef PIC_EXP_STAMP
-    __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const unsigned long long st1 = wall_clock64();
-    __builtin_amdgcn_sched_barrier(0);
-#endif
-#pragma unroll
-    for (int t = 0; t < PIC_TILES; ++t) {
-      T* xs = reinterpret_cast<T*>(&xv[t]);
-      T* vs = reinterpret_cast<T*>(&vv[t]);
-#pragma unroll
-      for (int k = 0; k < VEC; ++k) {
-        T pv = kReadV ? vs[k] : T(0);
-        push_one<T, A, SHAPE, STAGE>(xs[k], pv, Es, acc, acc2, L, dx, rdx, dt, c_prev, c_cur, d_cur, c_next, Ng, ke, bad);
-        if (kReadV) vs[k] = pv;
-      }
-      if (kStore) {
-        PIC_STORE(xv[t], reinterpret_cast<V*>(xe + i + (long long)t * step));
-        if (kStoreV) PIC_STORE(vv[t], reinterpret_cast<V*>(ve + i + (long long)t * step));
-      }
-    }
-#ifdef PIC_EXP_STAMP
-    __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    const unsigned long long st2 = wall_clock64();
-    __builtin_amdgcn_sched_barrier(0);
-    st_mem += st1 - st0;
-    st_cmp += st2 - st1;
-    st_n += 1;
-#endif
-  }
-#ifdef PIC_EXP_STAMP
-  if (tid == 0 && (STAGE == ST_C)) {
-    atomicAdd(&bad_count[1], st_mem);
-    atomicAdd(&bad_count[2], st_cmp);
-    atomicAdd(&bad_count[3], st_n);
-  }
-#endif
-  for (; i + VEC <= end; i += step) {          // leftover whole tiles
-    V xv = PIC_LOAD(reinterpret_cast<const V*>(xe + i));
-    V vv = {};
-    if (kReadV) vv = PIC_LOAD(reinterpret_cast<const V*>(ve + i));
-    T* xs = reinterpret_cast<T*>(&xv);
-    T* vs = reinterpret_cast<T*>(&vv);
-#pragma unroll
-    for (int k = 0; k < VEC; ++k) {
-      T pv = kReadV ? vs[k] : T(0);
-      push_one<T, A, SHAPE, STAGE>(xs[k], pv, Es, acc, acc2, L, dx, rdx, dt, c_prev, c_cur, d_cur, c_next, Ng, ke, bad);
-      if (kReadV) vs[k] = pv;
-    }
-    if (kStore) {
-      PIC_STORE(xv, reinterpret_cast<V*>(xe + i));
-      if (kStoreV) PIC_STORE(vv, reinterpret_cast<V*>(ve + i));
-    }
-  }
-#else
-  // Software pipeline (double buffer).  The next tile's loads are issued by inline asm BEFORE the current
-  // tile is pushed: written as plain C loads, hipcc proves they cannot alias the stores and sinks them back
-  // down to their use, so memory wait and push never overlap (stamped: 2.0 us + 1.8 us per iteration, all
-  // waves of a SIMD in lockstep).  hipcc does not count asm loads in its own s_waitcnt, so the wait is
-  // explicit: in issue order the younger VMEM operations at that point are exactly this iteration's stores
-  // (kNumStores), hence vmcnt(kNumStores).  The "+v" ties keep every use of the prefetched registers behind
-  // the wait (cdna_hip_programming.md 5.7).
-  constexpr int kNumStores = kStore ? (kStoreV ? 2 : 1) : 0;
-  bool have = (i + VEC <= end);
-  V cx = {}, cv = {};
-  if (have) {
-    cx = PIC_LOAD(reinterpret_cast<const V*>(xe + i));
-    if (kReadV) cv = PIC_LOAD(reinterpret_cast<const V*>(ve + i));
-  }
-#ifdef PIC_EXP_STAMP
-  unsigned long long st_mem = 0, st_cmp = 0, st_n = 0;
-#endif
-  while (have) {
-    const long long in = i + step;
-    const bool hn = (in + VEC <= end);
-    V nx = {}, nv = {};
-#ifdef PIC_EXP_STAMP
-    __builtin_amdgcn_sched_barrier(0);
-    const unsigned long long st0 = wall_clock64();
-    __builtin_amdgcn_sched_barrier(0);
-#endif
-    if (hn) {
-      if (kReadV)
-        asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %3, off"
-                     : "=&v"(nx), "=&v"(nv) : "v"(xe + in), "v"(ve + in) : "memory");
-      else
-        asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(nx) : "v"(xe + in) : "memory");
-    }
-    T* xs = reinterpret_cast<T*>(&cx);
-    T* vs = reinterpret_cast<T*>(&cv);
-#pragma unroll
-    for (int k = 0; k < VEC; ++k) {
-      T pv = kReadV ? vs[k] : T(0);
-      push_one<T, A, SHAPE, STAGE>(xs[k], pv, Es, acc, acc2, L, dx, rdx, dt, c_prev, c_cur, d_cur, c_next, Ng, ke, bad);
-      if (kReadV) vs[k] = pv;
-    }
-    if (kStore) {
-      PIC_STORE(cx, reinterpret_cast<V*>(xe + i));
-      if (kStoreV) PIC_STORE(cv, reinterpret_cast<V*>(ve + i));
-    }
-#ifdef PIC_EXP_STAMP
-    __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    const unsigned long long st1 = wall_clock64();
-    __builtin_amdgcn_sched_barrier(0);
-#endif
-    if (kNumStores == 2) asm volatile("s_waitcnt vmcnt(2)" : "+v"(nx), "+v"(nv) : : "memory");
-    else if (kNumStores == 1) asm volatile("s_waitcnt vmcnt(1)" : "+v"(nx), "+v"(nv) : : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" : "+v"(nx), "+v"(nv) : : "memory");
-#ifdef PIC_EXP_STAMP
-    __builtin_amdgcn_sched_barrier(0);
-    const unsigned long long st2 = wall_clock64();
-    __builtin_amdgcn_sched_barrier(0);
-    st_cmp += st1 - st0;      // issue prefetch + push + issue stores
-    st_mem += st2 - st1;      // residual wait for the prefetched tile
-    st_n += 1;
-#endif
-    cx = nx;
-    cv = nv;
-    i = in;
-    have = hn;
-  }
-#ifdef PIC_EXP_STAMP
-  if (tid == 0 && (STAGE == ST_C)) {
-    atomicAdd(&bad_count[1], st_mem);
-    atomicAdd(&bad_count[2], st_cmp);
-    atomicAdd(&bad_count[3], st_n);
-  }
-#endif
-#endif
-  for (long long k = i; k < end; ++k) {       // ragged tail (fewer than VEC particles left for this lane)
-    T xq = xe[k];
-    T pv = kReadV ? ve[k] : T(0);
-    push_one<T, A, SHAPE, STAGE>(xq, pv, Es, acc, acc2, L, dx, rdx, dt, c_prev, c_cur, d_cur, c_next, Ng, ke, bad);
-    if (kStore) {
-      xe[k] = xq;
-      if (kStoreV) ve[k] = pv;
-    }
-  }
-  }   // runs
-#ifdef PIC_EXP_STAMPB
-  const unsigned long long sb2 = wall_clock64();      // this wave's loop is done
-#endif
-  __syncthreads();
-#ifdef PIC_EXP_STAMPB
-  const unsigned long long sb3 = wall_clock64();      // every wave's loop is done
-#endif
-
-#if defined(PIC_EXP_LEVEL) && PIC_EXP_LEVEL <= -1
-  if (ke < -1.0) part[0] = ke;           // timing experiment: no flush, no KE reduction
-  return;
-#endif
-  const size_t rowi = ((size_t)env * a.nblk + blk) * Ng;
-  flush_mesh<A, SHAPE>(acc_all, a.R, stride, Ng, part + rowi);
-  if (kDual) flush_mesh<A, SHAPE>(acc2_all, a.R, stride, Ng, part2 + rowi);
-
-  if (kDual) {
-    double w = wave_sum(ke);
-    if ((tid & 63) == 0) red[tid >> 6] = w;
-    __syncthreads();
-    if (tid == 0) {
-      double s = 0.0;
-      for (int k = 0; k < WAVES; ++k) s += red[k];
-      ke_part[(size_t)env * a.nblk + blk] = s;
-    }
-  }
-  if (bad) atomicAdd(bad_count, (unsigned long long)bad);
-#ifdef PIC_EXP_STAMPB
-  if (STAGE == ST_C && (tid & 63) == 0) {
-    const unsigned long long sb4 = wall_clock64();
-    // [1] prologue+loop of this wave, [2] wait for the slowest wave of the workgroup, [3] flush; counts in [0]'s upper bits unused
-    const bool late = (unsigned)(blockIdx.y * gridDim.x + blockIdx.x) >= 2048u;   // not in the first resident set
-    if (late) {
-      atomicAdd(&bad_count[1], ((sbz - sb0) << 32) | (sbe - sbz));     // zero LDS | field tile load
-      atomicAdd(&bad_count[2], ((sb1 - sbe) << 32) | (sb2 - sb1));     // barrier | loop
-      atomicAdd(&bad_count[3], ((sb3 - sb2) << 32) | 1ull);            // straggler wait | count
-    }
-    (void)sb4;
-  }
-#endif
-}
-
-// ---------------------------------------------------------------------------------------------
-// Field solve (one workgroup per environment).
-// Replaces Gaussian_Elimination_Periodic + dense grad matvec (src/env/solve.py:27-53,
-// src/env/util.py:99-103, pic.py:116-117).  With G_{j+1/2} = (phi_{j+1}-phi_j)/dx the 3-point
-// periodic Poisson equation reads G_{j+1/2} - G_{j-1/2} = b_j dx, so G = cumsum(b) dx - mean and
-// E_j = -(phi_{j+1}-phi_{j-1})/(2dx) = -(G_{j+1/2} + G_{j-1/2})/2.  phi follows from a second
-// scan and is returned with zero mean.
-// ---------------------------------------------------------------------------------------------
-constexpr int SBLOCK = 1024;         // field-solve workgroup: 16 waves
-constexpr int SWAVES = SBLOCK / 64;
-constexpr int SGROUPS = 4;           // slab rows are summed by 4 groups of 256 lanes
-
-// inputs / outputs of one field solve; a launch carries up to two independent ones (blockIdx.y), e.g. the
-// post-step refresh of step s and the first force evaluation of step s+1
-struct SolveIO {
-  const double* part;      // slab [env][nblk][Ng] to reduce
-  const double* ext;       // E_ext [env][Ng] or null
-  const double* ke_part;   // [env][nblk] or null
-  double *n, *Ef, *E, *phi, *KE, *PE, *PEr;   // any may be null
-};
-
-__global__ __launch_bounds__(SBLOCK) void field_solve_kernel(SolveIO io0, SolveIO io1, SolveArgs a) {
-  const SolveIO io = blockIdx.y == 0 ? io0 : io1;
-  const double* __restrict__ part = io.part;
-  const double* __restrict__ E_ext = io.ext;
-  const double* __restrict__ ke_part = io.ke_part;
-  double* __restrict__ n_out = io.n;
-  double* __restrict__ Ef_out = io.Ef;
-  double* __restrict__ E_out = io.E;
-  double* __restrict__ phi_out = io.phi;
-  double* __restrict__ KE_out = io.KE;
-  double* __restrict__ PE_out = io.PE;
-  double* __restrict__ PEr_out = io.PEr;
-  extern __shared__ __align__(16) unsigned char smem_raw[];
-  double* sb = reinterpret_cast<double*>(smem_raw);   // b, then G_{j+1/2}
-  double* se = sb + a.Ng;                             // E, then phi
-  double* sp = se + a.Ng;                             // [SGROUPS][Ng] partial row sums
-  __shared__ double ws[SWAVES];
-
-  const int tid = threadIdx.x;
-  const int env = a.env0 + blockIdx.x;
-  const int Ng = a.Ng;
-  const int m = (Ng + SBLOCK - 1) / SBLOCK;
-  const int lo = min(tid * m, Ng), hi = min(lo + m, Ng);
-
-  // density: slab rows summed in a fixed order (group g takes rows g, g+4, ...; 4 loads in flight per
-  // lane), scaled (interpolate.py:16-18), b = n - n0 (pic.py:116)
-  const double* slab = part + (size_t)env * a.nblk * Ng;
-  const int g = tid >> 8, lane = tid & 255;
-  for (int j = lane; j < Ng; j += 256) {
-    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0, s4 = 0.0, s5 = 0.0, s6 = 0.0, s7 = 0.0;
-    int b = g;
-    for (; b + 7 * SGROUPS < a.nblk; b += 8 * SGROUPS) {       // 8 independent loads in flight per lane
-      s0 += slab[(size_t)b * Ng + j];
-      s1 += slab[(size_t)(b + SGROUPS) * Ng + j];
-      s2 += slab[(size_t)(b + 2 * SGROUPS) * Ng + j];
-      s3 += slab[(size_t)(b + 3 * SGROUPS) * Ng + j];
-      s4 += slab[(size_t)(b + 4 * SGROUPS) * Ng + j];
-      s5 += slab[(size_t)(b + 5 * SGROUPS) * Ng + j];
-      s6 += slab[(size_t)(b + 6 * SGROUPS) * Ng + j];
-      s7 += slab[(size_t)(b + 7 * SGROUPS) * Ng + j];
-    }
-    for (; b < a.nblk; b += SGROUPS) s0 += slab[(size_t)b * Ng + j];
-    sp[g * Ng + j] = ((s0 + s1) + (s2 + s3)) + ((s4 + s5) + (s6 + s7));
-  }
-  __syncthreads();
-  for (int j = tid; j < Ng; j += SBLOCK) {
-    double s = (sp[j] + sp[Ng + j]) + (sp[2 * Ng + j] + sp[3 * Ng + j]);
-    double nj = s * a.scale;
-    if (n_out) n_out[(size_t)env * Ng + j] = nj;
-    sb[j] = nj - a.n0;
-  }
-  __syncthreads();
-
-  // G_{j+1/2} = dx * inclusive_scan(b)
-  double loc = 0.0;
-  for (int j = lo; j < hi; ++j) loc += sb[j];
-  double tot;
-  double run = block_excl_scan<SWAVES>(loc, ws, tot);
-  loc = 0.0;
-  for (int j = lo; j < hi; ++j) {
-    run += sb[j];
-    double gj = run * a.dx;
-    sb[j] = gj;
-    loc += gj;
-  }
-  const double gmean = block_sum<SWAVES>(loc, ws) / (double)Ng;   // syncs: all of sb is G now
-
-  // E_j = -(G_{j+1/2} + G_{j-1/2}) / 2, plus the external field for force evaluations (util.py:102-103)
-  double e2 = 0.0;
-  for (int j = tid; j < Ng; j += SBLOCK) {
-    double gp = sb[j] - gmean;
-    double gm = sb[j == 0 ? Ng - 1 : j - 1] - gmean;
-    double E = -0.5 * (gp + gm);
-    se[j] = E;
-    double Et = E_ext ? E + E_ext[(size_t)env * Ng + j] : E;
-    if (Ef_out) Ef_out[(size_t)env * Ng + j] = Et;
-    if (E_out) E_out[(size_t)env * Ng + j] = Et;
-    e2 += Et * Et;
-  }
-  const double S = block_sum<SWAVES>(e2, ws);
-  if (tid == 0) {
-    double pe = 0.5 * S * a.dx;                       // objective.py:33 / util.py:129
-    if (PEr_out) PEr_out[env] = pe;
-    if (PE_out) PE_out[env] = pe * a.N_over_L;        // util.py:130
-  }
-
-  if (KE_out) {
-    double k = 0.0;
-    for (int b = tid; b < a.nblk; b += SBLOCK) k += ke_part[(size_t)env * a.nblk + b];
-    k = block_sum<SWAVES>(k, ws);
-    if (tid == 0) KE_out[env] = 0.5 * k;              // util.py:144
-  }
-
-  if (phi_out) {
-    // phi_{j+1} = phi_j + dx G_{j+1/2}: exclusive scan, then remove the mean
-    loc = 0.0;
-    for (int j = lo; j < hi; ++j) loc += (sb[j] - gmean) * a.dx;
-    run = block_excl_scan<SWAVES>(loc, ws, tot);
-    double ploc = 0.0;
-    for (int j = lo; j < hi; ++j) {
-      se[j] = run;
-      ploc += run;
-      run += (sb[j] - gmean) * a.dx;
-    }
-    const double pmean = block_sum<SWAVES>(ploc, ws) / (double)Ng;
-    for (int j = tid; j < Ng; j += SBLOCK) phi_out[(size_t)env * Ng + j] = se[j] - pmean;
-  }
-}
-
-// PIC.E (pic.py:120) and the CIC bookkeeping attributes (pic.py:104-107), on demand.
-template <typename T, int SHAPE>
-__global__ __launch_bounds__(BLOCK) void gather_E_kernel(const T* __restrict__ x, const double* __restrict__ E_mesh,
-                                                         T* __restrict__ E_out, long long N, long long ld, int Ng,
-                                                         double Ld, double dxd) {
-  constexpr int OFF = (SHAPE == PIC_TSC) ? 1 : 0;
-  extern __shared__ __align__(16) unsigned char smem_raw[];
-  T* Es = reinterpret_cast<T*>(smem_raw);
-  const int env = blockIdx.y;
-  for (int i = threadIdx.x; i < Ng + 2; i += BLOCK) {
-    int node = i - OFF;
-    node = node < 0 ? node + Ng : (node >= Ng ? node - Ng : node);
-    Es[i] = (T)E_mesh[(size_t)env * Ng + node];
-  }
-  __syncthreads();
-  const T L = (T)Ld, dx = (T)dxd;
-  for (long long i = (long long)blockIdx.x * BLOCK + threadIdx.x; i < N; i += (long long)gridDim.x * BLOCK) {
-    T w[3], xw;
-    int j;
-    unsigned bad = 0;
-    locate<T, SHAPE>(x[(size_t)env * ld + i], L, dx, T(1) / dx, Ng, xw, j, w, bad);
-    E_out[(size_t)env * N + i] = gather_field<T, SHAPE>(Es, j, w);
-  }
-}
-
-template <typename T>
-__global__ __launch_bounds__(BLOCK) void cic_query_kernel(const T* __restrict__ x, long long N, int Ng, double Ld,
-                                                          double dxd, long long* __restrict__ jl,
-                                                          long long* __restrict__ jr, double* __restrict__ wl,
-                                                          double* __restrict__ wr) {
-  const T L = (T)Ld, dx = (T)dxd;
-  for (long long i = (long long)blockIdx.x * BLOCK + threadIdx.x; i < N; i += (long long)gridDim.x * BLOCK) {
-    T w[3], xw;
-    int j;
-    unsigned bad = 0;
-    locate<T, PIC_CIC>(x[i], L, dx, T(1) / dx, Ng, xw, j, w, bad);
-    if (jl) jl[i] = j;
-    if (jr) jr[i] = (j + 1 == Ng) ? 0 : j + 1;
-    if (wl) wl[i] = (double)w[0];
-    if (wr) wr[i] = (double)w[1];
-  }
-}
-
-// E_field.compute_E (src/control/actuator.py:54-63) for every environment:
-// E_ext[e][j] = sum_m basis_cos[j][m] a[e][m] + sum_m basis_sin[j][m] a[e][M+m].  The basis tables come from the
-// host mirror (they carry the reference's linspace(0, L, Ng) mesh, actuator.py:13).
-__global__ __launch_bounds__(BLOCK) void actuator_kernel(const double* __restrict__ bc, const double* __restrict__ bs,
-                                                         const double* __restrict__ act, double* __restrict__ ext,
-                                                         int Ng, int M) {
-  const int env = blockIdx.y;
-  const int j = blockIdx.x * BLOCK + threadIdx.x;
-  if (j >= Ng) return;
-  const double* a = act + (size_t)env * 2 * M;
-  double c = 0.0, s = 0.0;
-  for (int m = 0; m < M; ++m) c += bc[(size_t)j * M + m] * a[m];
-  for (int m = 0; m < M; ++m) s += bs[(size_t)j * M + m] * a[M + m];
-  ext[(size_t)env * Ng + j] = c + s;
-}
-
-// compute_E_k_spectrum rows 1..M (src/interpret/spectrum.py:16): Ek[m] = fft(E_mesh)[m] / Ng * 2.
-__global__ __launch_bounds__(BLOCK) void modes_kernel(const double* __restrict__ E_mesh, double* __restrict__ re,
-                                                      double* __restrict__ im, int Ng, int M) {
-  __shared__ double wr[WAVES], wi[WAVES];
-  const int env = blockIdx.y, m = blockIdx.x + 1;
-  double sr = 0.0, si = 0.0;
-  for (int j = threadIdx.x; j < Ng; j += BLOCK) {
-    // angle = 2 pi m j / Ng, reduced exactly in integers before the trig call
-    const long long r = ((long long)m * j) % Ng;
-    double sn, cs;
-    sincospi(2.0 * (double)r / (double)Ng, &sn, &cs);
-    const double e = E_mesh[(size_t)env * Ng + j];
-    sr += e * cs;
-    si -= e * sn;
-  }
-  sr = wave_sum(sr);
-  si = wave_sum(si);
-  if ((threadIdx.x & 63) == 0) { wr[threadIdx.x >> 6] = sr; wi[threadIdx.x >> 6] = si; }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    double a = 0.0, b = 0.0;
-    for (int w = 0; w < WAVES; ++w) { a += wr[w]; b += wi[w]; }
-    re[(size_t)env * M + (m - 1)] = a / Ng * 2.0;
-    im[(size_t)env * M + (m - 1)] = b / Ng * 2.0;
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
-// Device-side initial conditions (the distributions of src/env/dist.py:27-194, not its RNG stream).
-// Philox4x32-10 counter-based generator: particle i of environment e draws from counter (i, attempt)
-// under key (seed, e), so a sample is reproducible and independent of the launch geometry.
-// ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void philox4x32_10(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
-  for (int r = 0; r < 10; ++r) {
-    const uint32_t hi0 = __umulhi(0xD2511F53u, c[0]), lo0 = 0xD2511F53u * c[0];
-    const uint32_t hi1 = __umulhi(0xCD9E8D57u, c[2]), lo1 = 0xCD9E8D57u * c[2];
-    const uint32_t n0 = hi1 ^ c[1] ^ k0, n2 = hi0 ^ c[3] ^ k1;
-    c[0] = n0; c[1] = lo1; c[2] = n2; c[3] = lo0;
-    k0 += 0x9E3779B9u;
-    k1 += 0xBB67AE85u;
-  }
-}
-
-__device__ __forceinline__ double u01(uint32_t a, uint32_t b) {       // 53 random bits -> (0, 1)
-  const unsigned long long bits = ((unsigned long long)a << 21) ^ ((unsigned long long)b >> 11);
-  return ((double)bits + 0.5) * (1.0 / 9007199254740992.0);
-}
-
-// kind 0: two-stream, halves at +v0 / -v0 (dist.py:70-102); kind 1: bump-on-tail, int(N/(1+a)) bulk
-// particles from N(0,1) then the beam from N(v0, sigma) (dist.py:151-189, same ordering as high_indx).
-// Velocities are truncated to [-10, 10] like the reference's uniform proposal; then v *= 1 + A sin(2 pi
-// n_mode x / L) (src/env/pic.py:68).
-template <typename T>
-__global__ __launch_bounds__(BLOCK) void sample_kernel(T* __restrict__ x, T* __restrict__ v, long long N, long long ld,
-                                                       int kind, double a, double v0, double sigma, double A,
-                                                       int n_mode, double L, unsigned long long seed) {
-  const int env = blockIdx.y;
-  const long long n_first = kind == 0 ? N / 2 : (long long)((double)N * (1.0 / (1.0 + a)));
-  for (long long i = (long long)blockIdx.x * BLOCK + threadIdx.x; i < N; i += (long long)gridDim.x * BLOCK) {
-    double mu, sg;
-    if (kind == 0) { mu = i < n_first ? v0 : -v0; sg = sigma; }
-    else { mu = i < n_first ? 0.0 : v0; sg = i < n_first ? 1.0 : sigma; }
-    const uint32_t k0 = (uint32_t)seed ^ (0x85EBCA6Bu * (uint32_t)(env + 1)), k1 = (uint32_t)(seed >> 32);
-    uint32_t c[4] = {(uint32_t)i, (uint32_t)((unsigned long long)i >> 32), 0u, 0x50494331u};
-    philox4x32_10(c, k0, k1);
-    double xs = u01(c[0], c[1]) * L;
-    if (xs >= L) xs = 0.0;
-    double ua = u01(c[2], c[3]), vs = 0.0;
-    for (uint32_t attempt = 1; attempt < 64; ++attempt) {
-      uint32_t d[4] = {(uint32_t)i, (uint32_t)((unsigned long long)i >> 32), attempt, 0x50494332u};
-      philox4x32_10(d, k0, k1);
-      double sn, cs;
-      sincospi(2.0 * u01(d[0], d[1]), &sn, &cs);
-      vs = mu + sg * sqrt(-2.0 * log(ua)) * cs;
-      if (vs >= -10.0 && vs <= 10.0) break;
-      ua = u01(d[2], d[3]);                        // rejected (outside the proposal's support): redraw
-    }
-    vs *= 1.0 + A * sin(2.0 * 3.14159265358979323846 * n_mode * xs / L);
-    x[(size_t)env * ld + i] = (T)xs;
-    v[(size_t)env * ld + i] = (T)vs;
-  }
-}
-
-// np.histogram2d bin of `val` for edges = np.linspace(lo, hi, nb + 1) (edges[i] = lo + i*step, last = hi):
-// searchsorted(edges, val, 'right') - 1, the last edge inclusive, -1 for values outside [lo, hi].
-__device__ __forceinline__ int hist_bin(double val, double lo, double hi, double step, int nb) {
-  if (!(val >= lo && val <= hi)) return -1;
-  int b = (int)((val - lo) / step);
-  b = b < 0 ? 0 : (b > nb - 1 ? nb - 1 : b);
-  auto edge = [&](int i) { return i == nb ? hi : lo + (double)i * step; };
-  while (b > 0 && val < edge(b)) --b;
-  while (b < nb - 1 && val >= edge(b + 1)) ++b;
-  return b;
-}
-
-// Phase-space histogram of the KL diagnostic (src/control/objective.py:8-14): counts[env][ix][iv].
-template <typename T>
-__global__ __launch_bounds__(BLOCK) void phase_hist_kernel(const T* __restrict__ x, const T* __restrict__ v,
-                                                           unsigned* __restrict__ counts, long long N, long long ld,
-                                                           int nb, double L, double vmin, double vmax) {
-  const int env = blockIdx.y;
-  const double sx = (L - 0.0) / nb, sv = (vmax - vmin) / nb;      // np.linspace step = (stop - start) / div
-  unsigned* c = counts + (size_t)env * nb * nb;
-  for (long long i = (long long)blockIdx.x * BLOCK + threadIdx.x; i < N; i += (long long)gridDim.x * BLOCK) {
-    const int ix = hist_bin((double)x[(size_t)env * ld + i], 0.0, L, sx, nb);
-    const int iv = hist_bin((double)v[(size_t)env * ld + i], vmin, vmax, sv, nb);
-    if (ix >= 0 && iv >= 0) atomicAdd(&c[(size_t)ix * nb + iv], 1u);
-  }
-}
-
-// Streaming ceiling of this box for the sweeps' access shape: read two arrays, write two arrays, 16 B
-// per lane, same grid -- what a sweep would take if it did no arithmetic at all.
-__global__ __launch_bounds__(BLOCK) void stream_probe_kernel(double2* __restrict__ a, double2* __restrict__ b,
-                                                             long long n2, long long chunk2, double scale,
-                                                             int reverse, int work) {
-  const long long bid = reverse ? (long long)gridDim.x - 1 - blockIdx.x : blockIdx.x;
-  long long begin = bid * chunk2;
-  long long end = begin + chunk2 < n2 ? begin + chunk2 : n2;
-  for (long long i = begin + threadIdx.x; i < end; i += BLOCK) {
-    double2 u = a[i], w = b[i];
-    u.x *= scale; u.y *= scale; w.x *= scale; w.y *= scale;
-    for (int k = 0; k < work; ++k) {   // experiment: dependent fp64 work between the load and the store
-      u.x = fma(u.x, scale, w.x * 1e-300); w.x = fma(w.x, scale, u.y * 1e-300);
-      u.y = fma(u.y, scale, w.y * 1e-300); w.y = fma(w.y, scale, u.x * 1e-300);
-    }
-    a[i] = u;
-    b[i] = w;
-  }
-}
-
-}  // namespace
 
 // ---------------------------------------------------------------------------------------------
 // Host side
