@@ -125,6 +125,22 @@ int pic_get_cic(pic_handle* h, int env, int64_t* indx_l, int64_t* indx_r, double
 int pic_eval_field(pic_handle* h, const void* x, int mem_kind, const double* E_ext,
                    double* n, double* E_mesh, double* half_sum_E2_dx);
 
+/* compute_E with everything it can return (src/env/util.py:73-116, return_all=True) and the shape-function
+ * bookkeeping of compute_n / CIC / TSC (util.py:48-70, src/env/interpolate.py:4-44), on arbitrary positions.
+ * x: [num_envs][N] particle dtype (host or device); E_ext: NULL or host [num_envs][Ng] float64.  Host outputs,
+ * any may be NULL: E_part, phi_part [num_envs][N] (particle dtype) = E_mesh (incl. E_ext) and phi_mesh gathered
+ * at the particles; n, E_mesh, phi_mesh [num_envs][Ng] float64 (phi in the mean-zero gauge); idx (int64) and
+ * w (float64) [num_envs][3][N]: rows indx_l, indx_r, 0 / weight_l, weight_r, 0 for CIC and l, m, r for TSC.
+ * Does not modify the environments' state. */
+int pic_compute_E(pic_handle* h, const void* x, int mem_kind, const double* E_ext, void* E_part, void* phi_part,
+                  double* n, double* E_mesh, double* phi_mesh, int64_t* idx, double* w);
+
+/* Gaussian_Elimination_Periodic on the 3-point periodic Laplacian (src/env/solve.py:27-53 as called from
+ * util.py:99) + E_mesh = -grad @ phi (util.py:100): rhs host [num_envs][Ng] float64, summing to zero per
+ * environment as n - n0 does (otherwise the periodic problem has no solution) -> phi (mean zero), E_mesh; host,
+ * either may be NULL. */
+int pic_solve_poisson(pic_handle* h, const double* rhs, double* phi, double* E_mesh);
+
 /* Device-side actuator, E_field (src/control/actuator.py:4-63).  pic_set_actuator uploads the host
  * mirror's basis tables, basis_cos / basis_sin [Ng][max_mode] float64 (they carry the reference's
  * linspace(0, L, Ng) mesh).  pic_step_actions computes E_ext = basis_cos @ a[:M] + basis_sin @ a[M:]

@@ -50,6 +50,8 @@ SIGNATURES = {
     "pic_gather_E": [_vp, _vp, C.c_int],
     "pic_get_cic": [_vp, C.c_int, _vp, _vp, _vp, _vp],
     "pic_eval_field": [_vp, _vp, C.c_int, _vp, _vp, _vp, _vp],
+    "pic_compute_E": [_vp, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "pic_solve_poisson": [_vp, _vp, _vp, _vp],
     "pic_profile": [_vp, C.c_int],
     "pic_profile_read": [_vp, _dp, _i64p],
     "pic_set_actuator": [_vp, C.c_int, _vp, _vp],
@@ -235,6 +237,33 @@ class Handle:
         pe = np.empty(self.num_envs)
         self._chk(self.lib.pic_eval_field(self._h, _ptr(x), PIC_HOST, _ptr(e), _ptr(n), _ptr(E), _ptr(pe)))
         return n, E, pe
+
+    def compute_E(self, x, E_ext=None, particles=True, shape=False):
+        """compute_E(return_all=True) + shape bookkeeping on arbitrary positions.  Returns a dict with
+        n, E_mesh (incl. E_ext), phi_mesh [env][Ng]; E, phi [env][N] if `particles`; idx (int64), w [env][3][N]
+        if `shape` (rows l, r, - for CIC; l, m, r for TSC)."""
+        x = self._particles_in(x)
+        E_, N, Ng = self.num_envs, self.N, self.Ng
+        e = None if E_ext is None else np.ascontiguousarray(np.asarray(E_ext, dtype=np.float64).reshape(E_, Ng))
+        out = {"n": np.empty((E_, Ng)), "E_mesh": np.empty((E_, Ng)), "phi_mesh": np.empty((E_, Ng))}
+        if particles:
+            out["E"] = np.empty((E_, N), dtype=self.dtype)
+            out["phi"] = np.empty((E_, N), dtype=self.dtype)
+        if shape:
+            out["idx"] = np.empty((E_, 3, N), dtype=np.int64)
+            out["w"] = np.empty((E_, 3, N))
+        self._chk(self.lib.pic_compute_E(self._h, _ptr(x), PIC_HOST, _ptr(e), _ptr(out.get("E")), _ptr(out.get("phi")),
+                                         _ptr(out["n"]), _ptr(out["E_mesh"]), _ptr(out["phi_mesh"]),
+                                         _ptr(out.get("idx")), _ptr(out.get("w"))))
+        return out
+
+    def solve_poisson(self, rhs):
+        """Periodic 3-point Poisson solve of rhs [env][Ng] (zero sum) -> (phi with zero mean, E_mesh = -grad phi)."""
+        b = np.ascontiguousarray(np.asarray(rhs, dtype=np.float64).reshape(self.num_envs, self.Ng))
+        phi = np.empty_like(b)
+        E = np.empty_like(b)
+        self._chk(self.lib.pic_solve_poisson(self._h, _ptr(b), _ptr(phi), _ptr(E)))
+        return phi, E
 
     def device_ptrs(self):
         ps = [C.c_void_p() for _ in range(8)]

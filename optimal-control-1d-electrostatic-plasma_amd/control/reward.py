@@ -19,21 +19,15 @@ The phase-space histogram / KL divergence (objective.py:8-18) is a logged diagno
 """
 import numpy as np
 
-from .. import _abi
 from .._params import ParamMixin
+from ..env.util import probe_handle
 
 _TINY = 1e-12
-_probes = {}
 
 
 def _probe(N, N_mesh, L, n0, device=0):
-    """Single-environment handle used only to evaluate fields of host-supplied states."""
-    key = (int(N), int(N_mesh), float(L), float(n0), int(device))
-    if key not in _probes:
-        while len(_probes) >= 8:                      # keep the cache small: handles own device memory
-            _probes.pop(next(iter(_probes))).close()
-        _probes[key] = _abi.Handle(key[0], key[1], 1, key[2], key[3], 1.0, 5.0, "float64", None, "CIC", key[4])
-    return _probes[key]
+    """Single-environment handle used only to evaluate fields of host-supplied states (shared cache)."""
+    return probe_handle(N, N_mesh, L, n0, "CIC", device)
 
 
 def estimate_f(state, N_mesh, L, vmin, vmax, n0):

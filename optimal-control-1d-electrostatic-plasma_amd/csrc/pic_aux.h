@@ -30,21 +30,34 @@ __global__ __launch_bounds__(BLOCK) void gather_E_kernel(const T* __restrict__ x
   }
 }
 
-template <typename T>
-__global__ __launch_bounds__(BLOCK) void cic_query_kernel(const T* __restrict__ x, long long N, int Ng, double Ld,
-                                                          double dxd, long long* __restrict__ jl,
-                                                          long long* __restrict__ jr, double* __restrict__ wl,
-                                                          double* __restrict__ wr) {
+// Shape-function bookkeeping of every particle: mesh indices and weights as CIC / TSC return them
+// (interpolate.py:8-14: l = floor(x/dx), r = (l+1) mod Ng;  interpolate.py:26-36: m = floor(x/dx), l = (m-1) mod Ng,
+// r = (m+1) mod Ng).  x: [env][ld]; idx, w: [env][3][N], rows l, r, (unused) for CIC and l, m, r for TSC.
+template <typename T, int SHAPE>
+__global__ __launch_bounds__(BLOCK) void shape_query_kernel(const T* __restrict__ x, long long N, long long ld, int Ng,
+                                                            double Ld, double dxd, long long* __restrict__ idx,
+                                                            double* __restrict__ w_out) {
   const T L = (T)Ld, dx = (T)dxd;
+  const int env = blockIdx.y;
+  long long* je = idx + (size_t)env * 3 * N;
+  double* we = w_out + (size_t)env * 3 * N;
   for (long long i = (long long)blockIdx.x * BLOCK + threadIdx.x; i < N; i += (long long)gridDim.x * BLOCK) {
     T w[3], xw;
     int j;
     unsigned bad = 0;
-    locate<T, PIC_CIC>(x[i], L, dx, T(1) / dx, Ng, xw, j, w, bad);
-    if (jl) jl[i] = j;
-    if (jr) jr[i] = (j + 1 == Ng) ? 0 : j + 1;
-    if (wl) wl[i] = (double)w[0];
-    if (wr) wr[i] = (double)w[1];
+    locate<T, SHAPE>(x[(size_t)env * ld + i], L, dx, T(1) / dx, Ng, xw, j, w, bad);
+    if (SHAPE == PIC_CIC) {
+      je[i] = j;
+      je[N + i] = (j + 1 == Ng) ? 0 : j + 1;
+      je[2 * N + i] = 0;
+    } else {                                   // locate's j is the node m itself (LDS slot of node m-1)
+      je[i] = (j == 0) ? Ng - 1 : j - 1;
+      je[N + i] = j;
+      je[2 * N + i] = (j + 1 == Ng) ? 0 : j + 1;
+    }
+    we[i] = (double)w[0];
+    we[N + i] = (double)w[1];
+    we[2 * N + i] = (double)w[2];
   }
 }
 

@@ -108,6 +108,7 @@ struct pic_handle {
   double* aux_n = nullptr;        // eval_field outputs
   double* aux_E = nullptr;
   double* aux_pe = nullptr;
+  double* aux_phi = nullptr;      // pic_compute_E / pic_solve_poisson: potential of the probe solve
   double* KE = nullptr;
   double* PE = nullptr;
   double* PEr = nullptr;
@@ -266,11 +267,14 @@ SolveIO solve_io(pic_handle* h, const SolveOut& o) {
 }
 
 // one solve, or two independent ones in the same launch (second = nullptr for one)
-void launch_solve(pic_handle* h, const Lane& ln, const SolveOut& o, const SolveOut* second = nullptr) {
+// rhs_rows > 0: the "slab" is a caller-supplied right-hand side of that many rows per environment, taken as it
+// is (scale 1, n0 0) instead of a deposit to be turned into n - n0 (pic_solve_poisson)
+void launch_solve(pic_handle* h, const Lane& ln, const SolveOut& o, const SolveOut* second = nullptr, int rhs_rows = 0) {
   SolveArgs a;
   a.env0 = ln.env0;
   a.N = h->cfg.N; a.Ng = h->cfg.Ng; a.nblk = h->nblk; a.L = h->cfg.L; a.dx = h->dx; a.n0 = h->cfg.n0;
   a.scale = h->scale; a.N_over_L = (double)h->cfg.N / h->cfg.L;
+  if (rhs_rows > 0) { a.nblk = rhs_rows; a.scale = 1.0; a.n0 = 0.0; }
   const SolveIO io0 = solve_io(h, o);
   const SolveIO io1 = second ? solve_io(h, *second) : io0;
   prof_begin(h, ln.stream, 4);
@@ -301,6 +305,37 @@ int upload(pic_handle* h, void* dst_padded, const void* src, int mem_kind) {
                                hipMemcpyDeviceToDevice, h->stream));
   }
   return PIC_OK;
+}
+
+// mesh [env][Ng] gathered at the positions x [env][ld] with the handle's shape function -> out, dense [env][N]
+void launch_gather(pic_handle* h, const void* x, const double* mesh, void* out) {
+  long long gx = (h->cfg.N + BLOCK - 1) / BLOCK;
+  if (gx > 1024) gx = 1024;
+  dim3 grid((unsigned)gx, h->cfg.num_envs);
+  const size_t lds = ((size_t)h->cfg.Ng + 2) * h->esz;
+  const bool tsc = h->cfg.interpol == PIC_TSC;
+  if (h->cfg.particle_dtype == PIC_F64) {
+    if (tsc) hipLaunchKernelGGL((gather_E_kernel<double, PIC_TSC>), grid, dim3(BLOCK), lds, h->stream, (const double*)x, mesh, (double*)out, h->cfg.N, h->ld, h->cfg.Ng, h->cfg.L, h->dx);
+    else hipLaunchKernelGGL((gather_E_kernel<double, PIC_CIC>), grid, dim3(BLOCK), lds, h->stream, (const double*)x, mesh, (double*)out, h->cfg.N, h->ld, h->cfg.Ng, h->cfg.L, h->dx);
+  } else {
+    if (tsc) hipLaunchKernelGGL((gather_E_kernel<float, PIC_TSC>), grid, dim3(BLOCK), lds, h->stream, (const float*)x, mesh, (float*)out, h->cfg.N, h->ld, h->cfg.Ng, h->cfg.L, h->dx);
+    else hipLaunchKernelGGL((gather_E_kernel<float, PIC_CIC>), grid, dim3(BLOCK), lds, h->stream, (const float*)x, mesh, (float*)out, h->cfg.N, h->ld, h->cfg.Ng, h->cfg.L, h->dx);
+  }
+}
+
+// indices and weights of `nenv` environments' worth of positions x [nenv][ld] -> idx, w [nenv][3][N]
+void launch_shape_query(pic_handle* h, const void* x, int nenv, int shape, long long* idx, double* w) {
+  long long gx = (h->cfg.N + BLOCK - 1) / BLOCK;
+  if (gx > 1024) gx = 1024;
+  dim3 grid((unsigned)gx, nenv);
+  const bool tsc = shape == PIC_TSC;
+  if (h->cfg.particle_dtype == PIC_F64) {
+    if (tsc) hipLaunchKernelGGL((shape_query_kernel<double, PIC_TSC>), grid, dim3(BLOCK), 0, h->stream, (const double*)x, h->cfg.N, h->ld, h->cfg.Ng, h->cfg.L, h->dx, idx, w);
+    else hipLaunchKernelGGL((shape_query_kernel<double, PIC_CIC>), grid, dim3(BLOCK), 0, h->stream, (const double*)x, h->cfg.N, h->ld, h->cfg.Ng, h->cfg.L, h->dx, idx, w);
+  } else {
+    if (tsc) hipLaunchKernelGGL((shape_query_kernel<float, PIC_TSC>), grid, dim3(BLOCK), 0, h->stream, (const float*)x, h->cfg.N, h->ld, h->cfg.Ng, h->cfg.L, h->dx, idx, w);
+    else hipLaunchKernelGGL((shape_query_kernel<float, PIC_CIC>), grid, dim3(BLOCK), 0, h->stream, (const float*)x, h->cfg.N, h->ld, h->cfg.Ng, h->cfg.L, h->dx, idx, w);
+  }
 }
 
 int download(pic_handle* h, void* dst, const void* src_padded, int mem_kind) {
@@ -496,7 +531,7 @@ int pic_destroy(pic_handle* h) {
   if (h->act) hipFree(h->act);
   if (h->modes) hipFree(h->modes);
   void* bufs[] = {h->x, h->v, h->scratch, h->part, h->part2, h->part_b, h->ke_part, h->Ef, h->n, h->E_mesh, h->phi, h->ext,
-                  h->aux_n, h->aux_E, h->aux_pe, h->KE, h->bad};
+                  h->aux_n, h->aux_E, h->aux_pe, h->aux_phi, h->KE, h->bad};
   for (void* b : bufs)
     if (b) hipFree(b);
   if (h->h_scal) hipHostFree(h->h_scal);
@@ -770,18 +805,7 @@ int pic_gather_E(pic_handle* h, void* E_particles, int mem_kind) {
     if (rc) return rc;
     dst = h->scratch;     // dense [env][N] fits in [env][ld]
   }
-  long long gx = (h->cfg.N + BLOCK - 1) / BLOCK;
-  if (gx > 1024) gx = 1024;
-  dim3 grid((unsigned)gx, h->cfg.num_envs);
-  const size_t lds = ((size_t)h->cfg.Ng + 2) * h->esz;
-  const bool tsc = h->cfg.interpol == PIC_TSC;
-  if (h->cfg.particle_dtype == PIC_F64) {
-    if (tsc) hipLaunchKernelGGL((gather_E_kernel<double, PIC_TSC>), grid, dim3(BLOCK), lds, h->stream, (const double*)h->x, h->E_mesh, (double*)dst, h->cfg.N, h->ld, h->cfg.Ng, h->cfg.L, h->dx);
-    else hipLaunchKernelGGL((gather_E_kernel<double, PIC_CIC>), grid, dim3(BLOCK), lds, h->stream, (const double*)h->x, h->E_mesh, (double*)dst, h->cfg.N, h->ld, h->cfg.Ng, h->cfg.L, h->dx);
-  } else {
-    if (tsc) hipLaunchKernelGGL((gather_E_kernel<float, PIC_TSC>), grid, dim3(BLOCK), lds, h->stream, (const float*)h->x, h->E_mesh, (float*)dst, h->cfg.N, h->ld, h->cfg.Ng, h->cfg.L, h->dx);
-    else hipLaunchKernelGGL((gather_E_kernel<float, PIC_CIC>), grid, dim3(BLOCK), lds, h->stream, (const float*)h->x, h->E_mesh, (float*)dst, h->cfg.N, h->ld, h->cfg.Ng, h->cfg.L, h->dx);
-  }
+  launch_gather(h, h->x, h->E_mesh, dst);
   HIPCHK(h, hipGetLastError());
   if (mem_kind == PIC_HOST)
     HIPCHK(h, hipMemcpyAsync(E_particles, dst, (size_t)h->cfg.num_envs * h->cfg.N * h->esz, hipMemcpyDeviceToHost, h->stream));
@@ -797,15 +821,10 @@ int pic_get_cic(pic_handle* h, int env, int64_t* indx_l, int64_t* indx_r, double
   const long long N = h->cfg.N;
   long long* dj = nullptr;
   double* dw = nullptr;
-  HIPCHK(h, hipMalloc((void**)&dj, 2 * N * sizeof(long long)));
-  if (hipMalloc((void**)&dw, 2 * N * sizeof(double)) != hipSuccess) { hipFree(dj); return fail(h, PIC_ENOMEM, "pic_get_cic: hipMalloc"); }
-  long long gx = (N + BLOCK - 1) / BLOCK;
-  if (gx > 1024) gx = 1024;
+  HIPCHK(h, hipMalloc((void**)&dj, 3 * N * sizeof(long long)));
+  if (hipMalloc((void**)&dw, 3 * N * sizeof(double)) != hipSuccess) { hipFree(dj); return fail(h, PIC_ENOMEM, "pic_get_cic: hipMalloc"); }
   const char* xe = (const char*)h->x + (size_t)env * h->ld * h->esz;
-  if (h->cfg.particle_dtype == PIC_F64)
-    hipLaunchKernelGGL(cic_query_kernel<double>, dim3((unsigned)gx), dim3(BLOCK), 0, h->stream, (const double*)xe, N, h->cfg.Ng, h->cfg.L, h->dx, dj, dj + N, dw, dw + N);
-  else
-    hipLaunchKernelGGL(cic_query_kernel<float>, dim3((unsigned)gx), dim3(BLOCK), 0, h->stream, (const float*)xe, N, h->cfg.Ng, h->cfg.L, h->dx, dj, dj + N, dw, dw + N);
+  launch_shape_query(h, xe, 1, PIC_CIC, dj, dw);
   hipError_t e = hipGetLastError();
   if (e == hipSuccess && indx_l) e = hipMemcpyAsync(indx_l, dj, N * sizeof(long long), hipMemcpyDeviceToHost, h->stream);
   if (e == hipSuccess && indx_r) e = hipMemcpyAsync(indx_r, dj + N, N * sizeof(long long), hipMemcpyDeviceToHost, h->stream);
@@ -842,6 +861,84 @@ int pic_eval_field(pic_handle* h, const void* x, int mem_kind, const double* E_e
   if (E_mesh) HIPCHK(h, hipMemcpyAsync(E_mesh, h->aux_E, gbytes, hipMemcpyDeviceToHost, h->stream));
   if (half_sum_E2_dx)
     HIPCHK(h, hipMemcpyAsync(half_sum_E2_dx, h->aux_pe, (size_t)h->cfg.num_envs * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return PIC_OK;
+}
+
+int pic_compute_E(pic_handle* h, const void* x, int mem_kind, const double* E_ext, void* E_part, void* phi_part,
+                  double* n, double* E_mesh, double* phi_mesh, int64_t* idx, double* w) {
+  if (!h || !x) return fail(h, PIC_EINVAL, "pic_compute_E: null argument");
+  HIPCHK(h, hipSetDevice(h->cfg.device_id));
+  int rc = ensure_scratch(h);
+  if (rc) return rc;
+  rc = upload(h, h->scratch, x, mem_kind);
+  if (rc) return rc;
+  const int E_ = h->cfg.num_envs;
+  const long long N = h->cfg.N;
+  const size_t gbytes = (size_t)E_ * h->cfg.Ng * sizeof(double);
+  if (!h->aux_phi) HIPCHK(h, hipMalloc((void**)&h->aux_phi, gbytes));
+  const double* ext = nullptr;
+  if (E_ext) {
+    HIPCHK(h, hipMemcpyAsync(h->ext, E_ext, gbytes, hipMemcpyHostToDevice, h->stream));
+    ext = h->ext;
+  }
+  Lane ln = whole(h);
+  launch_sweep(h, ln, ST_PROBE, h->scratch, h->scratch, 0, 0, 0);
+  SolveOut o;
+  o.ext = ext; o.n = h->aux_n; o.E = h->aux_E; o.phi = h->aux_phi; o.PEr = h->aux_pe;
+  launch_solve(h, ln, o);
+  HIPCHK(h, hipGetLastError());
+  if (n) HIPCHK(h, hipMemcpyAsync(n, h->aux_n, gbytes, hipMemcpyDeviceToHost, h->stream));
+  if (E_mesh) HIPCHK(h, hipMemcpyAsync(E_mesh, h->aux_E, gbytes, hipMemcpyDeviceToHost, h->stream));
+  if (phi_mesh) HIPCHK(h, hipMemcpyAsync(phi_mesh, h->aux_phi, gbytes, hipMemcpyDeviceToHost, h->stream));
+
+  // gathers at the particles and shape bookkeeping go through one temporary, sized for the larger of the two
+  void* tmp = nullptr;
+  const size_t part_bytes = (size_t)E_ * N * h->esz;
+  const size_t shape_bytes = (size_t)E_ * 3 * N * 8;
+  const bool want_shape = idx || w;
+  if (E_part || phi_part || want_shape) {
+    if (hipMalloc(&tmp, want_shape ? 2 * shape_bytes : part_bytes) != hipSuccess)
+      return fail(h, PIC_ENOMEM, "pic_compute_E: hipMalloc of the gather buffer");
+  }
+  hipError_t e = hipSuccess;
+  const double* meshes[2] = {h->aux_E, h->aux_phi};
+  void* outs[2] = {E_part, phi_part};
+  for (int k = 0; k < 2 && e == hipSuccess; ++k) {
+    if (!outs[k]) continue;
+    launch_gather(h, h->scratch, meshes[k], tmp);
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(outs[k], tmp, part_bytes, hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);      // tmp is reused
+  }
+  if (want_shape && e == hipSuccess) {
+    long long* dj = static_cast<long long*>(tmp);
+    double* dw = reinterpret_cast<double*>(static_cast<char*>(tmp) + shape_bytes);
+    launch_shape_query(h, h->scratch, E_, h->cfg.interpol, dj, dw);
+    e = hipGetLastError();
+    if (e == hipSuccess && idx) e = hipMemcpyAsync(idx, dj, shape_bytes, hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess && w) e = hipMemcpyAsync(w, dw, shape_bytes, hipMemcpyDeviceToHost, h->stream);
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+  if (tmp) hipFree(tmp);
+  if (e != hipSuccess) return fail(h, PIC_EHIP, std::string("pic_compute_E: ") + hipGetErrorString(e));
+  return PIC_OK;
+}
+
+int pic_solve_poisson(pic_handle* h, const double* rhs, double* phi, double* E_mesh) {
+  if (!h || !rhs) return fail(h, PIC_EINVAL, "pic_solve_poisson: null argument");
+  HIPCHK(h, hipSetDevice(h->cfg.device_id));
+  const size_t gbytes = (size_t)h->cfg.num_envs * h->cfg.Ng * sizeof(double);
+  if (!h->aux_phi) HIPCHK(h, hipMalloc((void**)&h->aux_phi, gbytes));
+  // aux_n doubles as the one-row "slab" holding the right-hand side; the solve reads it before it writes n
+  HIPCHK(h, hipMemcpyAsync(h->aux_n, rhs, gbytes, hipMemcpyHostToDevice, h->stream));
+  Lane ln = whole(h);
+  SolveOut o;
+  o.slab = h->aux_n; o.E = h->aux_E; o.phi = h->aux_phi;
+  launch_solve(h, ln, o, nullptr, 1);
+  HIPCHK(h, hipGetLastError());
+  if (phi) HIPCHK(h, hipMemcpyAsync(phi, h->aux_phi, gbytes, hipMemcpyDeviceToHost, h->stream));
+  if (E_mesh) HIPCHK(h, hipMemcpyAsync(E_mesh, h->aux_E, gbytes, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   return PIC_OK;
 }

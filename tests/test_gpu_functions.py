@@ -1,0 +1,108 @@
+"""Function-level drop-ins of src/env/{util,interpolate,solve}.py against the golden
+vectors the reference produced (tests/golden/g1-g3).  Everything runs through the C ABI (pic_compute_E,
+pic_eval_field, pic_solve_poisson)."""
+import numpy as np
+import pytest
+
+from conftest import load_golden, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def mods():
+    import ocplasma_amd  # noqa: F401
+    from ocplasma_amd.env import interpolate, solve, util
+    return util, interpolate, solve
+
+
+def test_CIC_and_TSC_functions_match_the_reference(mods):
+    util, interp, _ = mods
+    g = load_golden("g1_deposit")
+    L, Ng, n0 = float(g["L"]), int(g["Ng"]), float(g["n0"])
+    dx = L / Ng
+    x = g["x"].copy()
+    n, jl, jr, wl, wr = interp.CIC(x, n0, L, x.shape[0], Ng, dx)
+    assert np.array_equal(x, g["x"])                                   # CIC does not modify its input
+    assert jl.shape == (x.shape[0], 1) and jl.dtype == np.int64 and wl.shape == (x.shape[0], 1)
+    assert rel_err(n, g["n"]) < 1e-13
+    assert np.array_equal(jl, g["jl"]) and np.array_equal(jr, g["jr"])
+    assert np.array_equal(wl, g["wl"]) and np.array_equal(wr, g["wr"])  # bit for bit
+    # edge inputs: 0, just below L, negative, beyond L
+    xd = g["xin"].copy()
+    n, jl, jr, wl, wr = interp.CIC(xd, n0, L, xd.shape[0], Ng, dx)
+    assert rel_err(n, g["n_d"]) < 1e-13
+    assert np.array_equal(jl, g["jl_d"]) and np.array_equal(jr, g["jr_d"])
+    assert np.array_equal(wl, g["wl_d"]) and np.array_equal(wr, g["wr_d"])
+    n, jl, jm, jr, wl, wm, wr = interp.TSC(x, n0, L, x.shape[0], Ng, dx)
+    assert rel_err(n, g["tsc_n"]) < 1e-13
+    assert np.array_equal(jl, g["tsc_jl"]) and np.array_equal(jm, g["tsc_jm"]) and np.array_equal(jr, g["tsc_jr"])
+    for ours, ref in ((wl, g["tsc_wl"]), (wm, g["tsc_wm"]), (wr, g["tsc_wr"])):
+        assert np.max(np.abs(ours - ref)) < 1e-15
+
+
+def test_compute_n_and_compute_E_functions(mods):
+    util, _, _ = mods
+    g = load_golden("g3_compute_E")
+    L, Ng, n0 = float(g["L"]), int(g["Ng"]), float(g["n0"])
+    N, dx = g["x"].shape[0], L / Ng
+    # reference-style call: u is the (2N, 1) state, only u[:N] is read and it is wrapped in place
+    u = np.concatenate([g["x"] + L, 0.5 * g["x"]])                    # shifted by a box length on purpose
+    expect_wrapped = np.mod(u[:N], L)
+    E, E_mesh = util.compute_E(u, dx, Ng, n0, L, N)
+    assert np.array_equal(u[:N], expect_wrapped) and np.array_equal(u[N:], 0.5 * g["x"])
+    assert E.shape == (N, 1) and E_mesh.shape == (Ng, 1)
+    assert rel_err(E_mesh, g["E_mesh"]) < 1e-11 and rel_err(E, g["E"]) < 1e-11   # x + L - L costs a few ulp of x
+    u = np.concatenate([g["x"], 0.5 * g["x"]])
+    E, phi, E_mesh, phi_mesh = util.compute_E(u, dx, Ng, n0, L, N, util.generate_grad(L, Ng),
+                                              util.generate_laplacian(L, Ng), True, "CIC", g["E_ext"])
+    assert rel_err(E_mesh, g["E_mesh_with_ext"]) < 1e-12 and rel_err(E, g["E_with_ext"]) < 1e-12
+    gauge = g["phi_mesh"].mean()                                        # the reference's gauge is round-off
+    assert rel_err(phi_mesh, g["phi_mesh"] - gauge) < 1e-10
+    assert rel_err(phi, g["phi"] - gauge) < 1e-10
+    assert abs(phi_mesh.mean()) < 1e-12
+    E, E_mesh = util.compute_E(u, dx, Ng, n0, L, N, None, None, False, "TSC", g["E_ext"])
+    assert rel_err(E_mesh, g["tsc_E_mesh_with_ext"]) < 1e-12 and rel_err(E, g["tsc_E_with_ext"]) < 1e-12
+
+    g1 = load_golden("g1_deposit")
+    L1, Ng1 = float(g1["L"]), int(g1["Ng"])
+    x = g1["x"].copy()
+    n = util.compute_n(x, L1 / Ng1, Ng1, float(g1["n0"]), L1, x.shape[0])
+    assert n.shape == (Ng1,) and rel_err(n, g1["n"]) < 1e-13
+    assert np.array_equal(x, g1["x_wrapped"])                           # single np.mod, as util.py:51 leaves it
+    out = util.compute_n(g1["x"].copy(), L1 / Ng1, Ng1, float(g1["n0"]), L1, x.shape[0], True, "TSC")
+    assert len(out) == 7 and np.array_equal(out[2], g1["tsc_jm"]) and np.max(np.abs(out[5] - g1["tsc_wm"])) < 1e-15
+    out = util.compute_n(g1["x"].copy(), L1 / Ng1, Ng1, float(g1["n0"]), L1, x.shape[0], True)
+    assert len(out) == 5 and np.array_equal(out[1], g1["jl"]) and np.array_equal(out[4], g1["wr"])
+
+
+def test_energy_functions(mods):
+    util, _, _ = mods
+    g = load_golden("g3_compute_E")
+    L, Ng, n0 = float(g["L"]), int(g["Ng"]), float(g["n0"])
+    N, dx = g["x"].shape[0], L / Ng
+    x, v = g["x"].copy(), 0.5 * g["x"]
+    assert abs(util.compute_electric_energy(x, dx, N, Ng, n0, L) / float(g["PE"]) - 1) < 1e-12
+    assert abs(util.compute_hamiltonian(x, v, dx, N, Ng, n0, L) / float(g["H"]) - 1) < 1e-13
+
+
+def test_periodic_solver_function(mods):
+    util, _, solve = mods
+    g = load_golden("g2_solve")
+    L, n0 = float(g["L"]), float(g["n0"])
+    for Ng in (128, 250, 256, 1024):
+        A = util.generate_laplacian(L, Ng)
+        b = g[f"n_{Ng}"] - n0
+        phi = solve.Gaussian_Elimination_Periodic(A, b, gamma=5.0)
+        ref = g[f"phi_{Ng}_g5.0"]
+        assert phi.shape == (Ng,) and abs(phi.mean()) < 1e-12
+        # the reference's phi carries a round-off gauge and the conditioning of its singular solve
+        assert rel_err(phi, ref - ref.mean()) < 1e-9, Ng
+        assert np.max(np.abs(A @ phi - (b - b.mean()))) < 1e-9 * np.max(np.abs(b))      # it solves the system
+        phi2, E = solve.solve_periodic_poisson(b, L / Ng)
+        assert np.array_equal(phi2, phi)
+        assert rel_err(E, g[f"E_{Ng}_g5.0"]) < 5e-12 and rel_err(E, g[f"E_{Ng}_g0.3"]) < 5e-11
+    with pytest.raises(ValueError):
+        solve.Gaussian_Elimination_Periodic(np.eye(16), np.zeros(16))                 # not a Laplacian
+    with pytest.raises(ValueError):
+        solve.Gaussian_Elimination_Periodic(util.generate_laplacian(L, 16), np.zeros(15))

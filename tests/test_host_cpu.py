@@ -140,3 +140,19 @@ def test_product_never_imports_oracle():
         for f in fs:
             if f.endswith((".py", ".hip", ".h")):
                 assert "oracle" not in open(os.path.join(dp, f)).read(), f
+
+
+def test_dense_operator_mirrors_and_solver_argument_checks():
+    """env/util.generate_grad / generate_laplacian are bit-identical to the oracle's (which the golden vectors pin
+    through the reference's solves); solve.Gaussian_Elimination_Periodic rejects what the device solver does not
+    handle before anything touches the GPU."""
+    from ocplasma_amd.env import solve, util
+    from oracle import pic_oracle as po
+    for L, Ng in ((50.0, 8), (50.0, 250), (10.0, 129)):
+        assert np.array_equal(util.generate_grad(L, Ng), po.dense_grad(L, Ng))
+        assert np.array_equal(util.generate_laplacian(L, Ng), po.dense_laplacian(L, Ng))
+        assert abs(solve._laplacian_spacing(util.generate_laplacian(L, Ng)) / (L / Ng) - 1) < 1e-15
+    for bad in (np.eye(16), np.zeros((16, 16)), np.ones((4, 5)), util.generate_grad(50.0, 16),
+                util.generate_laplacian(50.0, 16) + np.diag(np.full(16, 1e-3))):
+        with pytest.raises(ValueError):
+            solve._laplacian_spacing(bad)
