@@ -178,6 +178,15 @@ class PIC:
         self._invalidate()
         self._fields_hidden = False
 
+    def compute_state_gradient(self, eta: np.ndarray, E_external: Optional[np.ndarray] = None):
+        """pic.py:125-129: d/dt [x; v] = [v; -E(x)] for an arbitrary (2N, 1) state.  `update_state` does not go
+        through this (the sub-stages are fused into the sweeps); it is here for callers that drive their own
+        integrator.  Like the reference it wraps eta[:N] in place; the field comes from the device."""
+        from .util import compute_E
+        force = compute_E(eta, self.dx, self.N_mesh, self.n0, self.L, self.N, None, None, False, self.interpol,
+                          E_external, device=self.device)[0]
+        return np.concatenate([eta[self.N:, :], -force], axis=0)
+
     def update_state(self, E_external: Optional[np.ndarray] = None):
         """pic.py:131-146: one Yoshida-4 step with an optional external mesh field (Ng,1)."""
         h = self._ensure_handle()

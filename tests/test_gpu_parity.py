@@ -640,6 +640,13 @@ def test_pic_api_corners(oc, po):
     sim.update_density()
     sim.update_E_field()
     assert rel_err(sim.n, ref.n) < 1e-12
+    # compute_state_gradient (pic.py:125-129) on an arbitrary state, with and without an external field
+    eta = np.concatenate([ref.x + 0.3, 1.7 * ref.v])
+    for ext in (None, 0.1 * np.random.default_rng(1).normal(size=(int(g["Ng"]), 1))):
+        ours = sim.compute_state_gradient(eta.copy(), ext)
+        theirs = ref.state_gradient(eta.copy(), ext)
+        assert ours.shape == theirs.shape == (2 * sim.N, 1)
+        assert np.array_equal(ours[:sim.N], theirs[:sim.N]) and rel_err(ours[sim.N:], theirs[sim.N:]) < 1e-11
     sim.close()
     # float32 drop-in: the API still hands out float64 arrays
     s32 = make_pic(oc, g, dtype="float32")
