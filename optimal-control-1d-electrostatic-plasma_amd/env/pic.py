@@ -128,20 +128,28 @@ class PIC:
             self._cache["E"] = self._ensure_handle().gather_E()[0].astype(np.float64).reshape(-1, 1)
         return self._cache["E"]
 
-    def _cic(self):
-        if "cic" not in self._cache:
-            if self.interpol != "CIC":
-                raise NotImplementedError("indx_*/weight_* are exposed for CIC only")
-            jl, jr, wl, wr = self._ensure_handle().cic(0)
-            self._cache["cic"] = (jl.reshape(-1, 1), jr.reshape(-1, 1), wl.reshape(-1, 1), wr.reshape(-1, 1))
-        return self._cache["cic"]
+    def _shape(self):
+        """indx_* / weight_* of the current particles as update_density leaves them (pic.py:93-112):
+        (l, r) for CIC, (l, m, r) for TSC, each an (N, 1) column."""
+        if "shape" not in self._cache:
+            h = self._ensure_handle()
+            if self.interpol == "CIC":
+                jl, jr, wl, wr = h.cic(0)
+                cols = {"indx_l": jl, "indx_r": jr, "weight_l": wl, "weight_r": wr, "indx_m": None, "weight_m": None}
+            else:
+                out = h.compute_E(self._particles()[0], None, particles=False, shape=True)
+                idx, w = out["idx"][0], out["w"][0]
+                cols = {"indx_l": idx[0], "indx_m": idx[1], "indx_r": idx[2],
+                        "weight_l": w[0], "weight_m": w[1], "weight_r": w[2]}
+            self._cache["shape"] = {k: (None if a is None else a.reshape(-1, 1)) for k, a in cols.items()}
+        return self._cache["shape"]
 
-    indx_l = property(lambda self: self._cic()[0])
-    indx_r = property(lambda self: self._cic()[1])
-    weight_l = property(lambda self: self._cic()[2])
-    weight_r = property(lambda self: self._cic()[3])
-    indx_m = property(lambda self: None)
-    weight_m = property(lambda self: None)
+    indx_l = property(lambda self: self._shape()["indx_l"])
+    indx_m = property(lambda self: self._shape()["indx_m"])
+    indx_r = property(lambda self: self._shape()["indx_r"])
+    weight_l = property(lambda self: self._shape()["weight_l"])
+    weight_m = property(lambda self: self._shape()["weight_m"])
+    weight_r = property(lambda self: self._shape()["weight_r"])
 
     # -- reference methods -------------------------------------------------------------------
     def initialize(self):

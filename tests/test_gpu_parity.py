@@ -174,9 +174,13 @@ def test_g4_external_field_steps(oc, name, interpol):
             assert rel_err(sim.E, g["E_1"]) < 1e-11
             p, pr = sim.phi_mesh, g["phi_mesh_1"]
             assert rel_err(p, pr - pr.mean()) < 1e-9
+            assert np.array_equal(sim.indx_l, g["indx_l_1"]) and np.array_equal(sim.indx_r, g["indx_r_1"])
+            assert rel_err(sim.weight_l, g["weight_l_1"]) < 1e-9 and rel_err(sim.weight_r, g["weight_r_1"]) < 1e-9
             if interpol == "CIC":
-                assert np.array_equal(sim.indx_l, g["indx_l_1"]) and np.array_equal(sim.indx_r, g["indx_r_1"])
-                assert rel_err(sim.weight_l, g["weight_l_1"]) < 1e-9 and rel_err(sim.weight_r, g["weight_r_1"]) < 1e-9
+                assert sim.indx_m is None and sim.weight_m is None
+            else:                                               # pic.py:98-99, 109-110
+                assert np.array_equal(sim.indx_m, (sim.indx_l + 1) % Ng)
+                assert np.max(np.abs(sim.weight_l + sim.weight_m + sim.weight_r - 1)) < 1e-14
     assert circ_err(sim.x, g["x_20"], L) / L < 1e-10 and rel_err(sim.v, g["v_20"]) < 1e-10
     assert rel_err(sim.E_mesh, g["E_mesh_20"]) < 1e-9
     assert rel_err(H, g["H"]) < 1e-12
