@@ -125,6 +125,12 @@ int pic_get_cic(pic_handle* h, int env, int64_t* indx_l, int64_t* indx_r, double
 int pic_eval_field(pic_handle* h, const void* x, int mem_kind, const double* E_ext,
                    double* n, double* E_mesh, double* half_sum_E2_dx);
 
+/* nsteps x PIC.update_state with the energies of every step kept, i.e. the E / PE traces PIC.simulate
+ * returns (pic.py:175-223) without its particle snapshots: hist, host [nsteps][3][num_envs] float64 =
+ * KE, PE, PE_reward after each step (total energy = KE + PE).  E_ext as in pic_step, constant over the steps.
+ * No host synchronisation between the steps; returns when the history has arrived. */
+int pic_step_history(pic_handle* h, const double* E_ext, int mem_kind, int nsteps, double* hist);
+
 /* compute_E with everything it can return (src/env/util.py:73-116, return_all=True) and the shape-function
  * bookkeeping of compute_n / CIC / TSC (util.py:48-70, src/env/interpolate.py:4-44), on arbitrary positions.
  * x: [num_envs][N] particle dtype (host or device); E_ext: NULL or host [num_envs][Ng] float64.  Host outputs,

@@ -61,6 +61,18 @@ __global__ __launch_bounds__(BLOCK) void shape_query_kernel(const T* __restrict_
   }
 }
 
+// energies of the step just finished -> slot `s` of a history [steps][3][num_envs] (KE, PE, PE_reward)
+__global__ __launch_bounds__(BLOCK) void record_energies_kernel(const double* __restrict__ KE, const double* __restrict__ PE,
+                                                                const double* __restrict__ PEr, double* __restrict__ hist,
+                                                                int s, int nenv) {
+  const int e = blockIdx.x * BLOCK + threadIdx.x;
+  if (e >= nenv) return;
+  double* slot = hist + (size_t)s * 3 * nenv;
+  slot[e] = KE[e];
+  slot[nenv + e] = PE[e];
+  slot[2 * nenv + e] = PEr[e];
+}
+
 // E_field.compute_E (src/control/actuator.py:54-63) for every environment:
 // E_ext[e][j] = sum_m basis_cos[j][m] a[e][m] + sum_m basis_sin[j][m] a[e][M+m].  The basis tables come from the
 // host mirror (they carry the reference's linspace(0, L, Ng) mesh, actuator.py:13).

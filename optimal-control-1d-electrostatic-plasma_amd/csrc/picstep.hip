@@ -738,6 +738,41 @@ int pic_step(pic_handle* h, const double* E_ext, int mem_kind, int nsteps) {
   return PIC_OK;
 }
 
+int pic_step_history(pic_handle* h, const double* E_ext, int mem_kind, int nsteps, double* hist) {
+  if (!h || !hist) return fail(h, PIC_EINVAL, "pic_step_history: null argument");
+  if (nsteps < 0) return fail(h, PIC_EINVAL, "pic_step_history: nsteps < 0");
+  if (nsteps == 0) return PIC_OK;
+  HIPCHK(h, hipSetDevice(h->cfg.device_id));
+  const int E = h->cfg.num_envs;
+  const size_t bytes = (size_t)nsteps * 3 * E * sizeof(double);
+  double* dh = nullptr;
+  HIPCHK(h, hipMalloc((void**)&dh, bytes));
+  // the external field is uploaded once; the per-step calls then take it from the device
+  const double* ext = E_ext;
+  int kind = mem_kind;
+  int rc = PIC_OK;
+  if (E_ext && mem_kind == PIC_HOST) {
+    hipError_t e = hipMemcpyAsync(h->ext, E_ext, (size_t)E * h->cfg.Ng * sizeof(double), hipMemcpyHostToDevice, h->stream);
+    if (e != hipSuccess) { hipFree(dh); return fail(h, PIC_EHIP, std::string("pic_step_history: ") + hipGetErrorString(e)); }
+    ext = h->ext;
+    kind = PIC_DEVICE;
+  }
+  for (int s = 0; s < nsteps && rc == PIC_OK; ++s) {
+    rc = pic_step(h, ext, kind, 1);
+    if (rc == PIC_OK)
+      hipLaunchKernelGGL(record_energies_kernel, dim3((E + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, h->stream, h->KE, h->PE,
+                         h->PEr, dh, s, E);
+  }
+  hipError_t e = hipGetLastError();
+  if (rc == PIC_OK && e == hipSuccess) e = hipMemcpyAsync(hist, dh, bytes, hipMemcpyDeviceToHost, h->stream);
+  hipError_t e2 = hipStreamSynchronize(h->stream);
+  hipFree(dh);
+  if (rc != PIC_OK) return rc;
+  if (e != hipSuccess || e2 != hipSuccess)
+    return fail(h, PIC_EHIP, std::string("pic_step_history: ") + hipGetErrorString(e != hipSuccess ? e : e2));
+  return PIC_OK;
+}
+
 int pic_get_particles(pic_handle* h, void* x, void* v, int mem_kind) {
   if (!h) return PIC_EINVAL;
   HIPCHK(h, hipSetDevice(h->cfg.device_id));

@@ -55,6 +55,18 @@ class BatchedPIC:
         """nsteps x update_state for every environment; asynchronous (call sync() or a getter)."""
         self._h.step(E_external, nsteps)
 
+    def simulate(self, nsteps: int, E_external: Optional[np.ndarray] = None):
+        """The energy traces of PIC.simulate (pic.py:175-223) for every environment, without its particle
+        snapshots: -> (E, PE), each [nsteps + 1, num_envs], entry 0 = the state before the first step, as the
+        reference records it.  The steps run back to back on the device; one read-back at the end."""
+        ke0, pe0, _ = self.energies()
+        ke, pe, _ = self._h.step_history(E_external, nsteps)
+        return np.concatenate([(ke0 + pe0)[None], ke + pe]), np.concatenate([pe0[None], pe])
+
+    def step_history(self, E_external: Optional[np.ndarray] = None, nsteps: int = 1):
+        """nsteps x update_state; -> (KE, PE, PE_reward) after every step, each [nsteps, num_envs]."""
+        return self._h.step_history(E_external, nsteps)
+
     def step_device(self, E_ext_ptr=0, nsteps: int = 1):
         self._h.step_device(E_ext_ptr, nsteps)
 

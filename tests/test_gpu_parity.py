@@ -281,6 +281,38 @@ def test_nsteps_in_one_call_equals_repeated_calls(oc, po):
     assert circ_err(xa[0], xa[1][::-1], L) / L < 1e-12 and rel_err(a.fields()[1][0], a.fields()[1][1]) < 1e-11
 
 
+def test_energy_history_equals_stepwise_reads(oc, po):
+    """pic_step_history / BatchedPIC.simulate: the E and PE traces of PIC.simulate, one read-back for all steps."""
+    E_, N, Ng, L, K = 3, 20000, 128, 50.0, 12
+    xs, vs = zip(*[po.synthetic_bump_on_tail(N, L, seed=40 + e) for e in range(E_)])
+    ext = 0.05 * np.random.default_rng(3).normal(size=(E_, Ng))
+    a = oc.BatchedPIC(E_, N, Ng, L=L, dt=0.1)
+    b = oc.BatchedPIC(E_, N, Ng, L=L, dt=0.1)
+    for env in (a, b):
+        env.reset(np.stack(xs), np.stack(vs))
+    H, PE = a.simulate(K, ext)
+    assert H.shape == PE.shape == (K + 1, E_)
+    ke0, pe0, _ = b.energies()
+    # two handles agree to rounding, not bit for bit: the order of the LDS atomics inside a workgroup is free
+    assert rel_err(H[0], ke0 + pe0) < 1e-14 and rel_err(PE[0], pe0) < 1e-12
+    for s in range(1, K + 1):
+        b.step(ext)
+        ke, pe, per = b.energies()
+        assert rel_err(H[s], ke + pe) < 1e-13 and rel_err(PE[s], pe) < 1e-10, s
+    xa, va = a.particles()
+    xb, vb = b.particles()
+    assert circ_err(xa, xb, L) / L < 1e-13 and rel_err(va, vb) < 1e-12
+    ke, pe, per = a.step_history(None, 2)
+    assert ke.shape == (2, E_) and np.array_equal(per[-1], a.energies()[2])     # same handle, same numbers
+    # against the oracle's own trace for environment 0
+    ref = po.OraclePIC(xs[0], vs[0], Ng, L=L, dt=0.1, perturb=False, faithful=False)
+    Href = [ref.get_energy()]
+    for _ in range(K):
+        ref.update_state(ext[0].reshape(-1, 1))
+        Href.append(ref.get_energy())
+    assert rel_err(H[:, 0], np.array(Href)) < 1e-12
+
+
 def test_sweep_A_is_skipped_only_when_its_deposit_is_already_there(oc, po):
     """Sweep D / reset also deposit the next step's q1, so sweep A normally never runs; loading
     particles without a refresh invalidates that deposit and must fall back to sweep A."""
