@@ -125,6 +125,15 @@ int pic_get_cic(pic_handle* h, int env, int64_t* indx_l, int64_t* indx_r, double
 int pic_eval_field(pic_handle* h, const void* x, int mem_kind, const double* E_ext,
                    double* n, double* E_mesh, double* half_sum_E2_dx);
 
+/* One environment step in three calls, each with its own external field: PIC.update_state_w_input_func
+ * (pic.py:148-163), where the field is a function of the sub-stage state.  Stage k (1, 2, 3, in this order)
+ * evaluates the force at q_k with E_ext (as in pic_step; NULL = none) and runs the sweep that kicks to p_k and
+ * drifts to q_{k+1}; stage 3 also wraps x and refreshes n / E_mesh / phi / energies.  Between the calls
+ * pic_get_particles returns the sub-stage state (q_{k+1} unwrapped, p_k) the caller's input function needs
+ * (before stage 1: q_1 = x + (c_1 v) dt with c_1 = 0.5 / (2 - 2^(1/3)), formed by the caller).  pic_step and
+ * pic_step_stage(1) are refused while a staged step is open; pic_reset / pic_set_particles abandon it. */
+int pic_step_stage(pic_handle* h, int stage, const double* E_ext, int mem_kind);
+
 /* nsteps x PIC.update_state with the energies of every step kept, i.e. the E / PE traces PIC.simulate
  * returns (pic.py:175-223) without its particle snapshots: hist, host [nsteps][3][num_envs] float64 =
  * KE, PE, PE_reward after each step (total energy = KE + PE).  E_ext as in pic_step, constant over the steps.

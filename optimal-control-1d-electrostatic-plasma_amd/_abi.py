@@ -41,6 +41,7 @@ SIGNATURES = {
     "pic_reset": [_vp, _vp, _vp, C.c_int],
     "pic_reset_sampled": [_vp, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int, C.c_uint64],
     "pic_step": [_vp, _vp, C.c_int, C.c_int],
+    "pic_step_stage": [_vp, C.c_int, _vp, C.c_int],
     "pic_step_history": [_vp, _vp, C.c_int, C.c_int, _vp],
     "pic_get_particles": [_vp, _vp, _vp, C.c_int],
     "pic_set_particles": [_vp, _vp, _vp, C.c_int],
@@ -238,6 +239,10 @@ class Handle:
         pe = np.empty(self.num_envs)
         self._chk(self.lib.pic_eval_field(self._h, _ptr(x), PIC_HOST, _ptr(e), _ptr(n), _ptr(E), _ptr(pe)))
         return n, E, pe
+
+    def step_stage(self, stage, E_ext=None):
+        e = None if E_ext is None else np.ascontiguousarray(np.asarray(E_ext, dtype=np.float64).reshape(self.num_envs, self.Ng))
+        self._chk(self.lib.pic_step_stage(self._h, int(stage), _ptr(e), PIC_HOST))
 
     def step_history(self, E_ext=None, nsteps=1):
         """nsteps steps; returns (KE, PE, PE_reward), each [nsteps][num_envs], the energies after every step."""

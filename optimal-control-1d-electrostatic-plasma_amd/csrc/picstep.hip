@@ -109,6 +109,7 @@ struct pic_handle {
   double* aux_E = nullptr;
   double* aux_pe = nullptr;
   double* aux_phi = nullptr;      // pic_compute_E / pic_solve_poisson: potential of the probe solve
+  int mid_stage = 0;              // pic_step_stage: force evaluations of the current step already done (0 = between steps)
   double* KE = nullptr;
   double* PE = nullptr;
   double* PEr = nullptr;
@@ -574,6 +575,7 @@ int pic_set_particles(pic_handle* h, const void* x, const void* v, int mem_kind)
   if (mem_kind == PIC_HOST) HIPCHK(h, hipStreamSynchronize(h->stream));
   h->has_state = true;
   h->q1_ready = false;
+  h->mid_stage = 0;
   return PIC_OK;
 }
 
@@ -591,10 +593,58 @@ int pic_reset(pic_handle* h, const void* x0, const void* v0, int mem_kind) {
   return refresh_fields(h);
 }
 
+int pic_step_stage(pic_handle* h, int stage, const double* E_ext, int mem_kind) {
+  if (!h) return PIC_EINVAL;
+  if (!h->has_state) return fail(h, PIC_ESTATE, "pic_step_stage: call pic_reset first");
+  if (stage < 1 || stage > 3 || stage != h->mid_stage + 1)
+    return fail(h, PIC_ESTATE, "pic_step_stage: stages run in the order 1, 2, 3");
+  HIPCHK(h, hipSetDevice(h->cfg.device_id));
+  const double* ext = nullptr;
+  if (E_ext) {
+    ext = E_ext;
+    if (mem_kind == PIC_HOST) {
+      HIPCHK(h, hipMemcpyAsync(h->ext, E_ext, (size_t)h->cfg.num_envs * h->cfg.Ng * sizeof(double),
+                               hipMemcpyHostToDevice, h->stream));
+      ext = h->ext;
+    }
+  }
+  const double* c = h->cs;
+  const double* d = h->ds;
+  Lane ln = whole(h);
+  ln.parity = h->sweep_parity;
+  SolveOut f;                      // force evaluation with THIS stage's external field
+  f.ext = ext; f.Ef = h->Ef;
+  if (stage == 1) {
+    if (h->q1_ready) {
+      f.slab = h->part2;           // q1 was deposited by the previous sweep D / reset
+    } else {
+      launch_sweep(h, ln, ST_A, h->x, h->v, 0.0, c[0], 0.0);
+    }
+    launch_solve(h, ln, f);
+    launch_sweep(h, ln, ST_B, h->x, h->v, c[0], c[1], d[1]);
+  } else if (stage == 2) {
+    launch_solve(h, ln, f);
+    launch_sweep(h, ln, ST_C, h->x, h->v, 0.0, c[2], d[2]);
+  } else {
+    launch_solve(h, ln, f);
+    launch_sweep(h, ln, ST_D, h->x, h->v, 0.0, c[3], d[3]);
+    SolveOut o;                    // post-step refresh: no external field (pic.py:114-117)
+    o.ke_part = h->ke_part; o.n = h->n; o.E = h->E_mesh; o.phi = h->phi;
+    o.KE = h->KE; o.PE = h->PE; o.PEr = h->PEr;
+    launch_solve(h, ln, o);
+    h->q1_ready = true;
+  }
+  h->sweep_parity = ln.parity;
+  h->mid_stage = stage == 3 ? 0 : stage;
+  HIPCHK(h, hipGetLastError());
+  return PIC_OK;
+}
+
 int pic_step(pic_handle* h, const double* E_ext, int mem_kind, int nsteps) {
   if (!h) return PIC_EINVAL;
   if (!h->has_state) return fail(h, PIC_ESTATE, "pic_step: call pic_reset first");
   if (nsteps < 0) return fail(h, PIC_EINVAL, "pic_step: nsteps < 0");
+  if (h->mid_stage) return fail(h, PIC_ESTATE, "pic_step: a staged step is in progress (finish pic_step_stage 1..3)");
   HIPCHK(h, hipSetDevice(h->cfg.device_id));
   const double* ext = nullptr;
   if (E_ext) {

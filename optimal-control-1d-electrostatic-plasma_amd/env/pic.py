@@ -207,9 +207,24 @@ class PIC:
         self._fields_hidden = False
 
     def update_state_w_input_func(self, input_func: Optional[Callable]):
-        # pic.py:148-163 re-evaluates input_func at every sub-stage state; nothing in the reference calls it
-        # (run_feedback.py:146 is commented out) and it would force a host round trip per sub-stage.
-        raise NotImplementedError("update_state_w_input_func is not part of the accelerated path")
+        """pic.py:148-163: a step whose external field is `input_func(eta)` of the sub-stage state.  The three
+        force evaluations whose result the integrator uses happen at [q1; p0], [q2; p1], [q3; p2]
+        (integration.py:32); `input_func` is called at exactly those states (the reference also calls it for the
+        evaluations whose field it discards).  Each call costs a host round trip of the state, by construction."""
+        if input_func is None:
+            return self.update_state(None)
+        h = self._ensure_handle()
+        x, v = self._particles()
+        c1 = 0.5 * (1 / (2 - 2 ** (1 / 3)))                        # integration.py:62-66, same expression order
+        eta = np.concatenate([x.reshape(-1, 1) + c1 * v.reshape(-1, 1) * self.dt, v.reshape(-1, 1)], axis=0)
+        for stage in (1, 2, 3):
+            field = input_func(eta)
+            h.step_stage(stage, None if field is None else np.asarray(field, dtype=np.float64).reshape(-1))
+            if stage < 3:
+                xs, vs = h.particles()
+                eta = np.concatenate([xs[0].astype(np.float64).reshape(-1, 1), vs[0].astype(np.float64).reshape(-1, 1)], axis=0)
+        self._invalidate()
+        self._fields_hidden = False
 
     def get_state(self):
         x, v = self._particles()

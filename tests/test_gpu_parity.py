@@ -701,6 +701,49 @@ def test_pic_api_corners(oc, po):
     sh.close()
 
 
+def test_update_state_w_input_func(oc, po):
+    """pic.py:148-163: the external field is a function of the sub-stage state.  Checked against the oracle's
+    Yoshida-4 composition driven by the same input function (3 steps)."""
+    g = load_golden("g4_bump_on_tail_ext_N4000_Ng256")
+    L, Ng, N = float(g["L"]), int(g["Ng"]), int(g["N"])
+    mesh = np.linspace(0, L, Ng).reshape(-1, 1)
+    calls = []
+
+    def input_func(eta):                    # a pure function of the (unwrapped) sub-stage state
+        calls.append(float(eta[:N].max()))
+        a = np.mean(np.cos(2 * np.pi * eta[:N] / L))
+        b = np.mean(eta[N:] ** 2)
+        return 0.3 * a * np.sin(2 * np.pi * mesh / L) + 0.02 * b * np.cos(4 * np.pi * mesh / L)
+
+    sim = make_pic(oc, g)
+    ref = po.OraclePIC(g["x0_raw"], g["v0_raw"], Ng, L=L, dt=float(g["dt_in"]), A=float(g["A"]), n_mode=int(g["n_mode"]),
+                       perturb=True, faithful=True)
+    assert sim.dt == ref.dt
+    for _ in range(3):
+        sim.update_state_w_input_func(input_func)
+        eta = np.concatenate([ref.x.reshape(-1, 1), ref.v.reshape(-1, 1)], axis=0)
+        eta = po.yoshida4(eta, lambda z: ref.state_gradient(z, input_func(z)), ref.dt)
+        ref.x, ref.v = np.mod(eta[:N], L), eta[N:]
+        ref.update_density()
+        ref.update_E_field()
+    assert circ_err(sim.x, ref.x, L) / L < 1e-13 and rel_err(sim.v, ref.v) < 1e-12
+    assert rel_err(sim.E_mesh, ref.E_mesh) < 1e-10 and abs(sim.get_energy() / ref.get_energy() - 1) < 1e-13
+    # None = plain update_state; the staged entry point enforces its order and blocks pic_step mid-step
+    sim.update_state_w_input_func(None)
+    ref.update_state(None)
+    assert circ_err(sim.x, ref.x, L) / L < 1e-13
+    h = sim._ensure_handle()
+    with pytest.raises(oc._abi.PicError, match="order"):
+        h.step_stage(2)
+    h.step_stage(1)
+    with pytest.raises(oc._abi.PicError, match="staged step"):
+        h.step(None, 1)
+    h.step_stage(2)
+    h.step_stage(3)
+    h.step(None, 1)
+    sim.close()
+
+
 def test_create_destroy_does_not_leak(oc, po):
     import torch
     N, Ng, L = 200_000, 256, 50.0
