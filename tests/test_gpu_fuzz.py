@@ -69,3 +69,48 @@ def test_random_shapes_against_oracle():
             checked += 1
         env.close()
     assert checked >= CASES          # most environments have a finite reference to compare with
+
+
+def test_random_shapes_function_level_mirrors():
+    """The module-function drop-ins (env.util / env.interpolate / env.solve) on random shapes against the oracle:
+    indices and weights bit for bit, densities / fields to rounding."""
+    import ocplasma_amd  # noqa: F401
+    from ocplasma_amd.env import interpolate, solve, util
+    from oracle import pic_oracle as po
+
+    rng = np.random.default_rng(77)
+    solved = 0
+    for _ in range(40):
+        N, Ng, L, n0, _dt, interpol, _envs, ext = _case(rng)
+        dx = L / Ng
+        x = rng.uniform(-0.25 * L, 1.25 * L, (N, 1))
+        tag = (N, Ng, L, n0, interpol, ext)
+        ours = (interpolate.CIC if interpol == "CIC" else interpolate.TSC)(x, n0, L, N, Ng, dx)
+        theirs = (po.cic if interpol == "CIC" else po.tsc)(x, n0, L, N, Ng, dx)
+        assert len(ours) == len(theirs), tag
+        assert rel_err(ours[0], theirs[0]) < 1e-12 or np.max(np.abs(ours[0] - theirs[0])) < 1e-12, tag
+        k = (len(ours) - 1) // 2
+        for a, b in zip(ours[1:1 + k], theirs[1:1 + k]):
+            # the oracle keeps floor(x/dx) unfolded where x/dx rounds up to Ng (interpolate.py:8); the device folds it
+            assert np.array_equal(a % Ng, b % Ng), tag
+        for a, b in zip(ours[1 + k:], theirs[1 + k:]):
+            assert np.max(np.abs(a - b)) < 1e-15 if interpol == "TSC" else np.array_equal(a, b), tag
+        E_ext = rng.uniform(-0.5, 0.5, (Ng, 1)) if ext else None
+        u = np.concatenate([x, rng.normal(size=(N, 1))])
+        E, phi, E_mesh, phi_mesh = util.compute_E(u.copy(), dx, Ng, n0, L, N, None, None, True, interpol, E_ext)
+        with np.errstate(all="ignore"):
+            Eo, Emo = po.field_at_particles(u.copy(), dx, Ng, n0, L, N, None, None, interpol, E_ext)
+        if not np.isfinite(Emo).all():
+            continue                          # singular Sherman-Morrison in the reference algorithm (DESIGN 2)
+        if np.max(np.abs(Emo)) > 1e-9:
+            assert rel_err(E_mesh, Emo) < 1e-8, tag
+            assert np.max(np.abs(E - Eo)) < 1e-8 * np.max(np.abs(Emo)), tag     # a lone particle feels ~0 (self-force)
+        assert abs(phi_mesh.mean()) < 1e-9 * max(1.0, np.abs(phi_mesh).max()), tag
+        # the returned potential solves the discrete Poisson problem for the returned density
+        n = util.compute_n(u.copy(), dx, Ng, n0, L, N, False, interpol)
+        lap = (np.roll(phi_mesh, -1, 0) - 2 * phi_mesh + np.roll(phi_mesh, 1, 0)) / dx ** 2
+        assert np.max(np.abs(lap[:, 0] - (n - n0))) < 1e-8 * max(1.0, np.abs(n).max()), tag
+        phi2 = solve.Gaussian_Elimination_Periodic(util.generate_laplacian(L, Ng), n - n0)
+        assert np.max(np.abs(phi2 - phi_mesh[:, 0])) < 1e-10 * max(1.0, np.abs(phi2).max()), tag
+        solved += 1
+    assert solved >= 25
