@@ -216,7 +216,7 @@ def main():
     total_ps = N * E * world * args.steps
     value = total_ps / elapsed
     out = {
-        "metric": "particle-steps/sec (N x envs x steps) at N=1e6, Ng=256; % HBM roofline",
+        "metric": "particle-steps/sec (N×envs×steps) at N=1e6, Ng=256; % HBM roofline",   # BASELINE.json, verbatim
         "value": value, "unit": "particle-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f64" if args.dtype == "float64" else "f32", "data": "synthetic",
