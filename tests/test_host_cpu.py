@@ -156,3 +156,21 @@ def test_dense_operator_mirrors_and_solver_argument_checks():
                 util.generate_laplacian(50.0, 16) + np.diag(np.full(16, 1e-3))):
         with pytest.raises(ValueError):
             solve._laplacian_spacing(bad)
+
+
+def test_bench_line_contract():
+    """bench.py prints BASELINE.json's metric verbatim and carries every key of the driver's contract plus the
+    roofline / cpu_baseline objects (static check: the bench itself needs the GPU)."""
+    import json
+    import re
+    src = open(os.path.join(ROOT, "bench.py"), encoding="utf-8").read()
+    metric = re.search(r'"metric": "([^"]+)"', src).group(1)
+    assert metric == json.load(open(os.path.join(ROOT, "BASELINE.json"), encoding="utf-8"))["metric"]
+    for key in ("value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert f'"{key}"' in src, key
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert f'"{key}"' in src, key
+    for key in ("value", "unit", "cores", "kind", "sample"):
+        assert f'"{key}"' in src, key
+    assert "torch.cuda.Event" not in src           # durations come from HIP events on the library's own stream
