@@ -16,20 +16,26 @@
 //             KE partials ; store x', p3 ; deposit(next q1 = x' + (c1 p3) dt) into a second mesh
 //   solve   : n, E_mesh (no E_ext), phi, KE, PE, PE_reward        (pic.py:145-146, util.py:119-147)
 //
-// 7 launches and 3 read+write passes over the particles per step (96 B per particle-step in fp64).
+// 7 launches for a lone step, 6 per step inside a multi-step call (the final solve shares a launch with the
+// next step's first one), 4 for small problems (force solves folded into the sweep prologues); 3 read+write
+// passes over the particles per step (96 B per particle-step in fp64).
 //
 // Arithmetic inside a sub-stage keeps the reference's operand order and is compiled with
 // -ffp-contract=off so that fp64 results track NumPy to rounding (tests/ hold the bounds).
 //
 // Deposit: every workgroup owns LDS copies of its environment's mesh (one per wave, `R` copies, two
-// sets in sweep D), accumulates with LDS float atomics (ds_add_f64; ds_add_f32 is selectable but
-// measured ~4x slower), then stores its partial mesh as one row of a slab [env][block][Ng] with plain
+// sets in sweep D), accumulates with LDS atomics (ds_add_f64; for float32 particles one packed ds_add_u64
+// per deposit, pic_device.h; ds_add_f32 is selectable but measured ~4x slower), then stores its partial mesh
+// as one row of a slab [env][block][Ng] with plain
 // coalesced stores.  The field-solve kernel sums the rows in a fixed order (no global atomics, no
 // memset between sweeps), scales to a density and solves the periodic Poisson problem with two prefix
 // scans.
 //
 // Compile-time switches (all off in the shipped build; results of each in profiles/experiments_r1.md):
 // PIC_EXP_* are timing/diagnostic experiments, PIC_PIPE / PIC_TILES alternative loop forms.
+//
+// Files: pic_device.h (per-particle helpers, scans), pic_sweep.h (push sweeps), pic_solve.h (field solve),
+// pic_aux.h (kernels off the step path); this file holds the handle, the launch schedule and the C ABI.
 
 #include <hip/hip_runtime.h>
 
