@@ -71,6 +71,23 @@ def _cpu_env(args):
     return steps, time.perf_counter() - t0
 
 
+def _host_cpu():
+    """'<model name>, <n> logical cores' of the box the baseline runs on (north star: core count stated)."""
+    model = "unknown CPU"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except AttributeError:
+        usable = os.cpu_count()
+    return f"{model}, {os.cpu_count()} logical cores ({usable} usable by this process)"
+
+
 def cpu_baseline(N, Ng, L, dt, budget_s=20.0, procs=1):
     """The NumPy oracle with the reference's call structure (7 compute_E + refresh per step, dense
     Ng x Ng operators, np.bincount) on a bounded sample of the same workload: one thread (how the
@@ -79,7 +96,7 @@ def cpu_baseline(N, Ng, L, dt, budget_s=20.0, procs=1):
         steps, el = _cpu_env((N, Ng, L, dt, budget_s, 1234))
         return {"value": N * steps / el, "unit": "particle-steps/s", "cores": 1, "kind": "port",
                 "sample": f"1 env of N={N}, Ng={Ng}, {steps} steps of the NumPy oracle (faithful call structure), "
-                          f"{el / steps * 1e3:.0f} ms/step"}
+                          f"{el / steps * 1e3:.0f} ms/step", "host": _host_cpu()}
     import multiprocessing as mp
     with mp.get_context("spawn").Pool(procs) as pool:
         t0 = time.perf_counter()
@@ -88,7 +105,8 @@ def cpu_baseline(N, Ng, L, dt, budget_s=20.0, procs=1):
     rate = sum(N * s / e for s, e in res)
     return {"value": rate, "unit": "particle-steps/s", "cores": procs, "kind": "port",
             "sample": f"{procs} processes x 1 env of N={N}, Ng={Ng}, {res[0][0]} steps each of the NumPy oracle "
-                      f"(faithful call structure), sum of per-process rates, {wall:.0f} s wall incl. start-up"}
+                      f"(faithful call structure), sum of per-process rates, {wall:.0f} s wall incl. start-up",
+            "host": _host_cpu()}
 
 
 def main():
