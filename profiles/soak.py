@@ -1,11 +1,13 @@
-"""Soak: config 2 (64 x 1e6 particles, Ng=256, fp64) for thousands of steps; health checks every 500 steps."""
+"""Soak: config 2 (64 x 1e6 particles, Ng=256; fp64, or float32 as argv[2]) for thousands of steps; health checks
+and elapsed time every 500 steps (the time column shows the sustained rate)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import ocplasma_amd
 from ocplasma_amd import BatchedPIC
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 5000
-env = BatchedPIC(64, 1_000_000, 256, L=50.0, dt=0.1)
+dtype = sys.argv[2] if len(sys.argv) > 2 else "float64"          # float32 = packed fixed-point LDS accumulator
+env = BatchedPIC(64, 1_000_000, 256, L=50.0, dt=0.1, dtype=dtype)
 env.reset_sampled("bump-on-tail", seed=2026)
 ke0, pe0, _ = env.energies()
 t0 = time.perf_counter()
