@@ -94,6 +94,12 @@ def load():
     if _lib is not None:
         return _lib
     path = library_path()
+    if not os.path.exists(path) and path == _build.LIB:
+        try:                                   # a checkout without the built library: compile it now (hipcc, gfx950)
+            _build.build_library()
+        except RuntimeError as e:
+            raise PicError(f"{path} is missing and could not be built ({e}). There is no CPU fallback for the "
+                           "PIC step.") from e
     if not os.path.exists(path):
         raise PicError(f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                        "(hipcc, gfx950). There is no CPU fallback for the PIC step.")
