@@ -32,13 +32,14 @@ def _compile(out, defines=(), verbose=False):
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         raise RuntimeError("hipcc not found: libpicstep.so can only be built with the ROCm toolchain")
-    cmd = [hipcc] + FLAGS + ["-D" + d for d in defines] + ["-o", out + ".tmp", SRC]
+    tmp = f"{out}.tmp.{os.getpid()}"           # several ranks may build at once: private file, atomic rename
+    cmd = [hipcc] + FLAGS + ["-D" + d for d in defines] + ["-o", tmp, SRC]
     if verbose:
         print(" ".join(cmd))
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("hipcc failed:\n" + r.stdout + r.stderr)
-    os.replace(out + ".tmp", out)
+    os.replace(tmp, out)
     return out
 
 
