@@ -269,11 +269,32 @@ class PIC:
         self.reinit()
         return self.get_state()
 
+    def set_actuator(self, actuator):
+        """Attach an `E_field` (src/control/actuator.py): `step(action)` then takes the 2*max_mode coefficient
+        vector the policies emit and builds E_external on the device (pic_step_actions)."""
+        self._actuator = actuator
+        self._actuator_key = None
+
+    def _step_action(self, action):
+        h = self._ensure_handle()
+        if getattr(self, "_actuator_key", None) != id(h):       # a re-created handle needs the tables again
+            h.set_actuator(self._actuator.basis_cos, self._actuator.basis_sin)
+            self._actuator_key = id(h)
+        h.step_actions(np.asarray(action, dtype=np.float64).reshape(1, -1), 1)
+        self._invalidate()
+        self._fields_hidden = False
+
     def step(self, E_external: Optional[np.ndarray] = None):
         """-> (obs, reward, done, info); reward = max(1 - PE_r, 0) of the PRE-step state, i.e. the
         electric-energy term of Reward.compute_reward (src/control/rl/reward.py:72) as the trainers
-        evaluate it (ddpg.py:455)."""
+        evaluate it (ddpg.py:455).  The argument is the mesh field E_external (N_mesh values) or, after
+        `set_actuator`, an action of 2*max_mode Fourier coefficients (cos, then sin: actuator.py:54-63)."""
         pe_pre = self.get_reward_electric_energy()
+        act = getattr(self, "_actuator", None)
+        if E_external is not None and act is not None and np.size(E_external) == 2 * act.max_mode != self.N_mesh:
+            self._step_action(E_external)
+            ke, pe, per = self._energies()
+            return self.get_state(), max(1.0 - pe_pre, 0.0), False, {"KE": ke, "PE": pe, "PE_reward": per}
         self.update_state(E_external)
         ke, pe, per = self._energies()
         info = {"KE": ke, "PE": pe, "PE_reward": per}

@@ -701,6 +701,30 @@ def test_pic_api_corners(oc, po):
     sh.close()
 
 
+def test_gym_step_takes_actions_through_the_device_actuator(oc):
+    """PIC.step(action): the coefficient vector a policy emits -> E_field on the device -> update_state; same
+    trajectory as handing update_state the host mirror's compute_E (golden g4 actions)."""
+    g = load_golden("g4_bump_on_tail_ext_N4000_Ng256")
+    L, Ng = float(g["L"]), int(g["Ng"])
+    mm = g["actions"].shape[1] // 2
+    a_env, b_env = make_pic(oc, g), make_pic(oc, g)
+    act = oc.E_field(L, Ng, mm)
+    a_env.set_actuator(act)
+    for k in range(5):
+        a = g["actions"][k]
+        obs, reward, done, info = a_env.step(a)
+        act.update_E(a[:mm], a[mm:])
+        pe_pre = b_env.get_reward_electric_energy()
+        b_env.update_state(E_external=act.compute_E())
+        assert obs.shape == (2 * a_env.N, 1) and done is False
+        assert abs(reward - max(1.0 - pe_pre, 0.0)) < 1e-12
+        assert abs(info["PE"] / b_env.get_electric_energy() - 1) < 1e-10
+    assert circ_err(a_env.x, b_env.x, L) / L < 1e-12 and rel_err(a_env.v, b_env.v) < 1e-12
+    assert circ_err(a_env.x, g["x_1"], L) > 0        # it did move on from step 1
+    a_env.close()
+    b_env.close()
+
+
 def test_update_state_w_input_func(oc, po):
     """pic.py:148-163: the external field is a function of the sub-stage state.  Checked against the oracle's
     Yoshida-4 composition driven by the same input function (3 steps)."""
