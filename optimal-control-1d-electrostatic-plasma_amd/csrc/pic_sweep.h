@@ -94,10 +94,16 @@ __device__ __forceinline__ void push_one(T& xq, T& vp, const T* __restrict__ Es,
   if (STAGE == ST_D || STAGE == ST_REFRESH) {
     q = xw;                                                     // pic.py:139 (+ util.py:51)
     ke += (double)p * (double)p;
+#if !defined(PIC_EXP_D) || PIC_EXP_D < 2               // timing experiments: 1 = no second deposit, 2 = no second locate either
     T qn = q + (c_next * p) * dt;                               // next step's q1 (integration.py:42, c1)
     T xn;
     locate<T, SHAPE>(qn, L, dx, rdx, Ng, xn, j, w, bad);
+#if defined(PIC_EXP_D) && PIC_EXP_D == 1
+    asm volatile("" ::"v"(w[0]), "v"(w[1]), "v"(j));
+#else
     deposit<A, T, SHAPE>(acc2, j, w);
+#endif
+#endif
   }
   xq = q;
   vp = p;
