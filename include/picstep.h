@@ -59,7 +59,8 @@ typedef struct pic_config {
   int32_t interpol;        /* PIC_CIC | PIC_TSC                                           */
   int32_t device_id;       /* HIP device ordinal                                          */
   int32_t blocks_per_env;  /* 0 = choose; workgroups streaming one environment per sweep  */
-  int32_t reserved;
+  int32_t env_index_base;  /* global index of environment 0 of this handle (0 for a single handle): keys the device
+                              sampler, so that a sharded ensemble does not depend on the number of ranks           */
 } pic_config;
 
 typedef struct pic_handle pic_handle;

@@ -13,8 +13,8 @@ Everything that steps particles goes through csrc/libpicstep.so (HIP, gfx950); t
 fallback.
 """
 from . import _abi, _build
-from .env import PIC, BatchedPIC, TwoStream, BumpOnTail
+from .env import PIC, BatchedPIC, ShardedPIC, TwoStream, BumpOnTail
 from .control import E_field, Reward
 from .interpret import compute_E_k_spectrum
 
-__all__ = ["PIC", "BatchedPIC", "TwoStream", "BumpOnTail", "E_field", "Reward", "compute_E_k_spectrum"]
+__all__ = ["PIC", "BatchedPIC", "ShardedPIC", "TwoStream", "BumpOnTail", "E_field", "Reward", "compute_E_k_spectrum"]

@@ -23,7 +23,7 @@ class PicConfig(C.Structure):
         ("N", C.c_int64), ("Ng", C.c_int32), ("num_envs", C.c_int32),
         ("L", C.c_double), ("n0", C.c_double), ("dt", C.c_double), ("gamma", C.c_double),
         ("particle_dtype", C.c_int32), ("accum_dtype", C.c_int32), ("interpol", C.c_int32),
-        ("device_id", C.c_int32), ("blocks_per_env", C.c_int32), ("reserved", C.c_int32),
+        ("device_id", C.c_int32), ("blocks_per_env", C.c_int32), ("env_index_base", C.c_int32),
     ]
 
 
@@ -127,7 +127,7 @@ class Handle:
     """Owns one pic_handle (one device, one stream, `num_envs` environments)."""
 
     def __init__(self, N, Ng, num_envs=1, L=50.0, n0=1.0, dt=0.1, gamma=5.0, particle_dtype="float64",
-                 accum_dtype=None, interpol="CIC", device_id=0, blocks_per_env=0):
+                 accum_dtype=None, interpol="CIC", device_id=0, blocks_per_env=0, env_index_base=0):
         self.lib = load()
         pd = {"float64": PIC_F64, "float32": PIC_F32}[str(np.dtype(particle_dtype))]
         # LDS mesh accumulator.  float64 particles: float64 (the parity mode).  float32 particles: "fixed" for
@@ -140,7 +140,8 @@ class Handle:
         else:
             ad = {"float64": PIC_F64, "float32": PIC_F32}[str(np.dtype(accum_dtype))]
         self.cfg = PicConfig(int(N), int(Ng), int(num_envs), float(L), float(n0), float(dt), float(gamma), pd, ad,
-                             {"CIC": PIC_CIC, "TSC": PIC_TSC}[interpol], int(device_id), int(blocks_per_env), 0)
+                             {"CIC": PIC_CIC, "TSC": PIC_TSC}[interpol], int(device_id), int(blocks_per_env),
+                             int(env_index_base))
         self.N, self.Ng, self.num_envs = int(N), int(Ng), int(num_envs)
         self.dtype = np.dtype(particle_dtype)
         self._h = C.c_void_p()

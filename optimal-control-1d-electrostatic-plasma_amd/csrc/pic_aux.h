@@ -144,14 +144,14 @@ __device__ __forceinline__ double u01(uint32_t a, uint32_t b) {       // 53 rand
 template <typename T>
 __global__ __launch_bounds__(BLOCK) void sample_kernel(T* __restrict__ x, T* __restrict__ v, long long N, long long ld,
                                                        int kind, double a, double v0, double sigma, double A,
-                                                       int n_mode, double L, unsigned long long seed) {
+                                                       int n_mode, double L, unsigned long long seed, int env_base) {
   const int env = blockIdx.y;
   const long long n_first = kind == 0 ? N / 2 : (long long)((double)N * (1.0 / (1.0 + a)));
   for (long long i = (long long)blockIdx.x * BLOCK + threadIdx.x; i < N; i += (long long)gridDim.x * BLOCK) {
     double mu, sg;
     if (kind == 0) { mu = i < n_first ? v0 : -v0; sg = sigma; }
     else { mu = i < n_first ? 0.0 : v0; sg = i < n_first ? 1.0 : sigma; }
-    const uint32_t k0 = (uint32_t)seed ^ (0x85EBCA6Bu * (uint32_t)(env + 1)), k1 = (uint32_t)(seed >> 32);
+    const uint32_t k0 = (uint32_t)seed ^ (0x85EBCA6Bu * (uint32_t)(env_base + env + 1)), k1 = (uint32_t)(seed >> 32);
     uint32_t c[4] = {(uint32_t)i, (uint32_t)((unsigned long long)i >> 32), 0u, 0x50494331u};
     philox4x32_10(c, k0, k1);
     double xs = u01(c[0], c[1]) * L;

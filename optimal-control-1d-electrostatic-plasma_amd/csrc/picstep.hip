@@ -366,6 +366,7 @@ int pic_create(const pic_config* cfg, pic_handle** out) {
   if (cfg->N < 1 || cfg->Ng < 4 || cfg->num_envs < 1 || !(cfg->L > 0) || !(cfg->dt > 0) || !(cfg->n0 > 0))
     return fail(nullptr, PIC_EINVAL, "pic_create: need N>=1, Ng>=4, num_envs>=1, L>0, dt>0, n0>0");
   if (cfg->num_envs > 65535) return fail(nullptr, PIC_EINVAL, "pic_create: num_envs > 65535");
+  if (cfg->env_index_base < 0) return fail(nullptr, PIC_EINVAL, "pic_create: env_index_base < 0");
   if (cfg->particle_dtype != PIC_F64 && cfg->particle_dtype != PIC_F32)
     return fail(nullptr, PIC_EINVAL, "pic_create: particle_dtype must be PIC_F64 or PIC_F32");
   if (cfg->accum_dtype != PIC_F64 && cfg->accum_dtype != PIC_F32 && cfg->accum_dtype != PIC_FIXED)
@@ -1101,10 +1102,10 @@ int pic_reset_sampled(pic_handle* h, int kind, double a, double v0, double sigma
   dim3 grid((unsigned)gx, h->cfg.num_envs);
   if (h->cfg.particle_dtype == PIC_F64)
     hipLaunchKernelGGL(sample_kernel<double>, grid, dim3(BLOCK), 0, h->stream, (double*)h->x, (double*)h->v, h->cfg.N,
-                       h->ld, kind, a, v0, sigma, A, n_mode, h->cfg.L, (unsigned long long)seed);
+                       h->ld, kind, a, v0, sigma, A, n_mode, h->cfg.L, (unsigned long long)seed, h->cfg.env_index_base);
   else
     hipLaunchKernelGGL(sample_kernel<float>, grid, dim3(BLOCK), 0, h->stream, (float*)h->x, (float*)h->v, h->cfg.N,
-                       h->ld, kind, a, v0, sigma, A, n_mode, h->cfg.L, (unsigned long long)seed);
+                       h->ld, kind, a, v0, sigma, A, n_mode, h->cfg.L, (unsigned long long)seed, h->cfg.env_index_base);
   HIPCHK(h, hipGetLastError());
   HIPCHK(h, hipMemsetAsync(h->bad, 0, sizeof(unsigned long long), h->stream));
   h->has_state = true;

@@ -30,6 +30,7 @@ class ShardedPIC:
         self.lo, self.hi = shard_range(self.rank, self.world, self.total_envs)
         self.num_local = self.hi - self.lo
         self.counts = [shard_range(r, self.world, self.total_envs) for r in range(self.world)]
+        env_factory_is_default = env_factory is None
         if env_factory is None:
             from .batched import BatchedPIC
 
@@ -37,6 +38,8 @@ class ShardedPIC:
                 return BatchedPIC(num_envs, N, N_mesh, **kw)
         if device is not None:
             env_kwargs["device"] = device
+        if env_factory_is_default:
+            env_kwargs.setdefault("env_index_base", self.lo)      # device sampler keyed by the GLOBAL environment index
         self.env = env_factory(self.num_local, N, N_mesh, **env_kwargs)
         self.N, self.N_mesh = N, N_mesh
 

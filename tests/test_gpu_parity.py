@@ -504,6 +504,48 @@ def test_run_wo_oc_shaped_driver():
     assert abs(out["J_KL"][0]) < 1.0 and np.isfinite(out["J_KL"]).all()
 
 
+def test_device_sampler_is_keyed_by_the_global_environment_index(oc):
+    """env_index_base: a handle holding environments [3, 5) of an ensemble draws exactly what a handle holding all of
+    them draws for those environments (what ShardedPIC relies on)."""
+    whole = oc.BatchedPIC(5, 3000, 64)
+    part = oc.BatchedPIC(2, 3000, 64, env_index_base=3)
+    for env in (whole, part):
+        env.reset_sampled("bump-on-tail", seed=77)
+    xw, vw = whole.particles()
+    xp, vp = part.particles()
+    assert np.array_equal(xw[3:], xp) and np.array_equal(vw[3:], vp)
+    assert not np.array_equal(xw[0], xw[3])
+    whole.close()
+    part.close()
+
+
+def test_sharded_rollout_example_two_ranks_one_device():
+    """examples/sharded_rollout.py under torch.distributed.run with 2 ranks (gloo, both on cuda:0): the gathered
+    returns are the single-process returns -- the ensemble does not depend on the number of ranks."""
+    import os
+    import re
+    import subprocess
+    import sys
+    from conftest import ROOT
+    script = os.path.join(ROOT, "examples", "sharded_rollout.py")
+    common = ["--envs", "6", "--particles", "20000", "--mesh", "64", "--steps", "8", "--backend", "gloo", "--same-device"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+
+    def returns_of(cmd):
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        m = re.search(r"episode returns: \[([^\]]*)\]", r.stdout.replace("\n", " "))
+        assert m, r.stdout
+        return np.array([float(t) for t in m.group(1).split()])
+
+    one = returns_of([sys.executable, script] + common)
+    two = returns_of([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                      "--master-addr", "127.0.0.1", "--master-port", "29533", script] + common)
+    assert one.shape == two.shape == (6,)
+    assert np.allclose(one, two, atol=2e-3)          # printed with 3 decimals
+    assert (one > 0).all() and (one <= 8).all()
+
+
 def test_feedback_control_loop_on_device():
     """run_feedback.py-shaped closed loop through modes -> action -> device actuator -> step: the
     controlled two-stream plasma must stay far below the free one's saturated field energy."""
