@@ -26,7 +26,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0                 # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-BYTES_PER_PARTICLE_STEP = {"float64": 112, "float32": 56}   # 14 words: 4 reads + 3 writes of (x, v)
+# SURVEY 8d's algorithmic figure: 14 words per particle-step (4 reads + 3 writes of x and v: four deposits need four
+# passes).  The schedule that ships moves 12 (sweep A's read is folded into the previous sweep D): 3 reads + 3 writes.
+ALGORITHMIC_BYTES_PER_PARTICLE_STEP = {"float64": 112, "float32": 56}
+MOVED_BYTES_PER_PARTICLE_STEP = {"float64": 96, "float32": 48}
 # algorithmic particle-array words moved by one launch of each sweep (reads + writes of x and v)
 SWEEP_WORDS = {"sweep_A": 2, "sweep_B": 4, "sweep_C": 4, "sweep_D": 4}
 
@@ -48,10 +51,12 @@ def synth_bump_on_tail_device(torch, num_envs, N, L, dtype, device, seed, a=0.2,
 def pmc_traffic(kernel, args, E, N, Ng):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (FETCH_SIZE x2 +
     WRITE_SIZE, profiles/summarize.py) -- only when they were taken on this exact workload."""
-    path = os.path.join(ROOT, "profiles", "r1_summary.json")
-    if not os.path.exists(path) or (E, N, Ng, args.dtype) != (64, 1_000_000, 256, "float64"):
-        return None
-    return json.load(open(path)).get("kernels", {}).get(kernel, {}).get("hbm_bytes_per_launch")
+    path = os.path.join(ROOT, "profiles", "r2_summary.json")
+    if not os.path.exists(path) or (E, N, Ng, args.dtype, args.positions) != (64, 1_000_000, 256, "float64", "float"):
+        return None, None
+    val = json.load(open(path)).get("kernels", {}).get(kernel, {}).get("hbm_bytes_per_launch")
+    return val, "profiles/r2_summary.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, " \
+                "not measured by this run)"
 
 
 def _cpu_env(args):
@@ -118,7 +123,8 @@ def main():
     ap.add_argument("--particles", type=int, default=1_000_000)
     ap.add_argument("--mesh", type=int, default=256)
     ap.add_argument("--dtype", default="float64", choices=["float64", "float32"])
-    ap.add_argument("--accum", default=None, choices=[None, "float64", "float32", "fixed"])
+    ap.add_argument("--accum", default=None, choices=[None, "fix64", "fixed", "float64"])
+    ap.add_argument("--positions", default="float", choices=["float", "fixed32"], help="fixed32: 32-bit fixed-point x (float32)")
     ap.add_argument("--blocks-per-env", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-procs", type=int, default=1, help="processes (one env each) for the CPU baseline")
@@ -160,7 +166,7 @@ def main():
     N, Ng, E, L = args.particles, args.mesh, args.envs, 50.0
     tdtype = torch.float64 if args.dtype == "float64" else torch.float32
     env = BatchedPIC(E, N, Ng, L=L, dt=0.1, device=dev_index, dtype=args.dtype, accum_dtype=args.accum,
-                     blocks_per_env=args.blocks_per_env)
+                     blocks_per_env=args.blocks_per_env, position_dtype=args.positions)
     local_rank = dev_index
     x0, v0 = synth_bump_on_tail_device(torch, E, N, L, tdtype, f"cuda:{local_rank}", seed=1234 + rank)
     torch.cuda.synchronize()
@@ -185,17 +191,27 @@ def main():
     t0 = time.perf_counter()
     env.step(None, nsteps=args.steps)
     env.sync()
+    t_steps = time.perf_counter() - t0              # this rank's K steps, before any collective
     returns = torch.as_tensor(env.rewards(), device=cdev)
+    t_g0 = time.perf_counter()
     if dist is not None:
         gathered = [torch.empty_like(returns) for _ in range(world)]
         dist.all_gather(gathered, returns)          # the one collective: per-environment returns
         returns = torch.cat(gathered)
+    t_gather = time.perf_counter() - t_g0           # includes waiting for the slowest rank to arrive
     barrier()
     elapsed = time.perf_counter() - t0
+    per_rank_ms = [t_steps / args.steps * 1e3]
+    gather_ms = [t_gather * 1e3]
     if dist is not None:
         t = torch.tensor([elapsed], device=cdev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        mine = torch.tensor([t_steps / args.steps * 1e3, t_gather * 1e3], device=cdev, dtype=torch.float64)
+        every = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)                # after the timed region: per-rank step time and gather time
+        per_rank_ms = [float(e[0]) for e in every]
+        gather_ms = [float(e[1]) for e in every]
 
     # health: nothing non-finite, energy conserved over the run
     ke, pe, _ = env.energies()
@@ -225,8 +241,9 @@ def main():
         avg_s = prof[dom][0] / prof[dom][1] * 1e-3
         alg_bytes = SWEEP_WORDS[dom] * esz * N * E
         ach = alg_bytes / avg_s / 1e9
+        traffic, traffic_source = pmc_traffic(dom, args, E, N, Ng)
         roof = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic(dom, args, E, N, Ng),
+                "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                 "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_s * 1e3,
                 "ms_per_step_with_event_brackets": ms_per_step_events,
                 "measured_inplace_copy_GBs": copy_gbs}
@@ -238,11 +255,17 @@ def main():
         "value": value, "unit": "particle-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f64" if args.dtype == "float64" else "f32", "data": "synthetic",
-        "config": {"workload": f"configs[1]: bump-on-tail, N={N}, Ng={Ng}, {E} envs per GPU, {args.dtype}, "
+        "config": {"workload": f"{'configs[1]: ' if (N, Ng, E, args.dtype) == (1_000_000, 256, 64, 'float64') else ''}"
+                               f"bump-on-tail, N={N}, Ng={Ng}, {E} envs per GPU, {args.dtype}"
+                               f"{' (fixed-point positions)' if args.positions == 'fixed32' else ''}, "
                                "no control (E_ext = None), Yoshida-4 step = PIC.update_state",
                    "envs_per_gpu": E, "particles_per_env": N, "mesh": Ng, "dt": env.dt,
                    "sharding": f"{world} x {E} envs, all-gather of returns only"},
-        "hbm_frac_of_step": value * BYTES_PER_PARTICLE_STEP[args.dtype] / (HBM_PEAK_GBS * 1e9),
+        # whole-step fractions of the 8 TB/s peak: on the bytes the schedule really moves (12 words per particle-step)
+        # and on SURVEY 8d's algorithmic count (14 words; > the first because sweep A's read is not made at all)
+        "hbm_frac_of_step": value / world * MOVED_BYTES_PER_PARTICLE_STEP[args.dtype] / (HBM_PEAK_GBS * 1e9),
+        "algorithmic_frac_of_step": value / world * ALGORITHMIC_BYTES_PER_PARTICLE_STEP[args.dtype] / (HBM_PEAK_GBS * 1e9),
+        "per_rank_ms_per_step": per_rank_ms, "returns_all_gather_ms": gather_ms,
         "energy_drift": drift, "bad_positions": bad, "mean_return": float(returns.mean().item()),
         "roofline": roof, "kernels": kernels,
     }

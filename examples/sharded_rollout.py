@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--gain", type=float, default=1.0)
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
     ap.add_argument("--same-device", action="store_true", help="every rank on cuda:0 (one-GPU rehearsal)")
+    ap.add_argument("--out", default=None, help="rank 0 saves the gathered returns and energies here (.npz, full precision)")
     args = ap.parse_args()
 
     import torch
@@ -67,6 +68,8 @@ def main():
               f"({rate:.3e} particle-steps/s incl. the per-step feedback round trip)")
         print("episode returns:", np.array2string(all_returns, precision=3, max_line_width=120))
         print(f"final field energy per env: min {all_energy[:, 2].min():.3e} max {all_energy[:, 2].max():.3e}")
+        if args.out:
+            np.savez(args.out, returns=all_returns, energies=all_energy)
     sh.close()
     if world > 1:
         dist.destroy_process_group()

@@ -26,10 +26,15 @@
 extern "C" {
 #endif
 
-#define PICSTEP_ABI_VERSION 1
+#define PICSTEP_ABI_VERSION 2
 
-enum { PIC_F64 = 0, PIC_F32 = 1,             /* particle / deposit-accumulator dtype          */
-       PIC_FIXED = 2 };                       /* accumulator only: packed 64-bit fixed point   */
+enum { PIC_F64 = 0, PIC_F32 = 1 };           /* particle dtype (velocities; positions too unless fixed point) */
+enum { PIC_POS_FLOAT = 0,                    /* positions stored in the particle dtype                         */
+       PIC_POS_FIXED32 = 1 };                 /* positions as 32-bit fixed point, x = u L / 2^32 (float32 particles) */
+enum { PIC_ACC_AUTO = 0,                     /* deposit accumulator: library's choice (PACKED for float32 CIC, else FIX64) */
+       PIC_ACC_FIX64 = 1,                     /* 64-bit integers, weights rounded to 2^-fg: order-independent sums    */
+       PIC_ACC_PACKED = 2,                    /* float32 particles, CIC: (count, sum of w_r) per cell in one word     */
+       PIC_ACC_F64 = 3 };                     /* float64 particles: float64 running sums in LDS (ds_add_f64)          */
 enum { PIC_CIC = 0, PIC_TSC = 1 };           /* src/env/interpolate.py:4 (CIC), :22 (TSC)     */
 enum { PIC_HOST = 0, PIC_DEVICE = 1 };       /* where a caller buffer lives                   */
 
@@ -53,14 +58,17 @@ typedef struct pic_config {
   double  dt;              /* time step (post-clamp)                                      */
   double  gamma;           /* unused by the scan solver                                   */
   int32_t particle_dtype;  /* PIC_F64 | PIC_F32                                           */
-  int32_t accum_dtype;     /* deposit accumulator in LDS: PIC_F64 | PIC_F32 | PIC_FIXED (the last two
-                              need F32 particles; PIC_FIXED is CIC only: count + sum of w_r in one
-                              64-bit word, 2^-24 weight resolution, one LDS atomic per deposit)       */
+  int32_t accum_dtype;     /* PIC_ACC_*: how a workgroup accumulates its deposit in LDS.  Every choice ends in the
+                              same global 64-bit fixed-point accumulators; FIX64 and PACKED are integer sums all
+                              the way and make a step bitwise reproducible                        */
   int32_t interpol;        /* PIC_CIC | PIC_TSC                                           */
   int32_t device_id;       /* HIP device ordinal                                          */
   int32_t blocks_per_env;  /* 0 = choose; workgroups streaming one environment per sweep  */
   int32_t env_index_base;  /* global index of environment 0 of this handle (0 for a single handle): keys the device
                               sampler, so that a sharded ensemble does not depend on the number of ranks           */
+  int32_t position_dtype;  /* PIC_POS_FLOAT | PIC_POS_FIXED32 (needs particle_dtype PIC_F32).  Fixed-point positions
+                              are handed over and returned as float32 like any float32 particle array; on the device
+                              they are uint32 (pic_device_ptrs' x)                                                  */
 } pic_config;
 
 typedef struct pic_handle pic_handle;
@@ -96,9 +104,16 @@ int pic_get_particles(pic_handle* h, void* x, void* v, int mem_kind);
 int pic_set_particles(pic_handle* h, const void* x, const void* v, int mem_kind);
 /* update_density + update_E_field on the current particles (pic.py:93-123). */
 int pic_refresh(pic_handle* h);
+/* The caller has written x or v through the device views of pic_device_ptrs (e.g. re-seeded finished
+ * environments on the device).  The handle caches the next step's first deposit (taken by the last sweep
+ * of the previous step); that cache no longer matches such particles.  pic_invalidate drops it, so that the
+ * next pic_step re-deposits from the stored particles (one extra read of x, v); pic_refresh does the same and
+ * also recomputes n / E_mesh / phi / energies.  One of the two MUST follow every external write. */
+int pic_invalidate(pic_handle* h);
 
 /* Zero-copy device views for torch: any pointer argument may be NULL. ld = leading dimension
- * (elements) of x and v; mesh arrays are dense. Valid until pic_destroy. */
+ * (elements) of x and v; mesh arrays are dense. Valid until pic_destroy.  The views are writable; a write to
+ * x or v must be followed by pic_invalidate or pic_refresh (see there). */
 int pic_device_ptrs(pic_handle* h, void** x, void** v, int64_t* ld, double** n, double** E_mesh, double** phi,
                     double** KE, double** PE, double** PE_reward);
 
@@ -120,7 +135,8 @@ int pic_get_cic(pic_handle* h, int env, int64_t* indx_l, int64_t* indx_r, double
 
 /* compute_E on arbitrary positions (src/env/util.py:73-116), used by compute_electric_energy
  * (util.py:119-131) and estimate_electric_energy (objective.py:20-35): deposit x -> solve ->
- * E_mesh (+E_ext).  Does not modify the environments' state.  x: [num_envs][N] particle dtype;
+ * E_mesh (+E_ext).  Does not modify the environments' state (probes have their own deposit accumulator and
+ * E_ext staging, so they may also run between pic_step_stage calls).  x: [num_envs][N] particle dtype;
  * E_ext: NULL or [num_envs][Ng] host float64; outputs (host, [num_envs][Ng] / [num_envs], any
  * may be NULL): n, E_mesh (with E_ext added), half_sum_E2_dx = 0.5*sum(E_mesh^2)*dx. */
 int pic_eval_field(pic_handle* h, const void* x, int mem_kind, const double* E_ext,

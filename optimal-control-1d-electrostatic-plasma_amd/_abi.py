@@ -10,10 +10,17 @@ import numpy as np
 
 from . import _build
 
-PIC_F64, PIC_F32, PIC_FIXED = 0, 1, 2
+PIC_F64, PIC_F32 = 0, 1
+PIC_POS_FLOAT, PIC_POS_FIXED32 = 0, 1
+PIC_ACC_AUTO, PIC_ACC_FIX64, PIC_ACC_PACKED, PIC_ACC_F64 = 0, 1, 2, 3
 PIC_CIC, PIC_TSC = 0, 1
 PIC_HOST, PIC_DEVICE = 0, 1
-ABI_VERSION = 1
+ABI_VERSION = 2
+
+# accum_dtype spellings of the Python layer -> PIC_ACC_*
+ACCUMULATORS = {None: PIC_ACC_AUTO, "auto": PIC_ACC_AUTO, "fix64": PIC_ACC_FIX64, "fixed": PIC_ACC_PACKED,
+                "packed": PIC_ACC_PACKED, "float64": PIC_ACC_F64}
+POSITION_FORMATS = {None: PIC_POS_FLOAT, "float": PIC_POS_FLOAT, "fixed32": PIC_POS_FIXED32}
 
 KIND_NAMES = ("sweep_A", "sweep_B", "sweep_C", "sweep_D", "field_solve", "sweep_aux", "", "")
 
@@ -24,6 +31,7 @@ class PicConfig(C.Structure):
         ("L", C.c_double), ("n0", C.c_double), ("dt", C.c_double), ("gamma", C.c_double),
         ("particle_dtype", C.c_int32), ("accum_dtype", C.c_int32), ("interpol", C.c_int32),
         ("device_id", C.c_int32), ("blocks_per_env", C.c_int32), ("env_index_base", C.c_int32),
+        ("position_dtype", C.c_int32),
     ]
 
 
@@ -46,6 +54,7 @@ SIGNATURES = {
     "pic_get_particles": [_vp, _vp, _vp, C.c_int],
     "pic_set_particles": [_vp, _vp, _vp, C.c_int],
     "pic_refresh": [_vp],
+    "pic_invalidate": [_vp],
     "pic_device_ptrs": [_vp] + [C.POINTER(_vp)] * 2 + [_i64p] + [C.POINTER(_vp)] * 6,
     "pic_get_fields": [_vp, _vp, _vp, _vp],
     "pic_get_energies": [_vp, _vp, _vp, _vp],
@@ -127,21 +136,23 @@ class Handle:
     """Owns one pic_handle (one device, one stream, `num_envs` environments)."""
 
     def __init__(self, N, Ng, num_envs=1, L=50.0, n0=1.0, dt=0.1, gamma=5.0, particle_dtype="float64",
-                 accum_dtype=None, interpol="CIC", device_id=0, blocks_per_env=0, env_index_base=0):
+                 accum_dtype=None, interpol="CIC", device_id=0, blocks_per_env=0, env_index_base=0,
+                 position_dtype=None):
         self.lib = load()
         pd = {"float64": PIC_F64, "float32": PIC_F32}[str(np.dtype(particle_dtype))]
-        # LDS mesh accumulator.  float64 particles: float64 (the parity mode).  float32 particles: "fixed" for
-        # CIC (count + sum of w_r packed in one 64-bit word, one integer LDS atomic per deposit), float64 for TSC;
-        # "float32" exists but ds_add_f32 deposits ~4x slower than ds_add_f64 on MI355X (profiles/experiments_r1.md)
-        if accum_dtype is None:
-            ad = PIC_FIXED if (pd == PIC_F32 and interpol == "CIC") else PIC_F64
-        elif str(accum_dtype) == "fixed":
-            ad = PIC_FIXED
-        else:
-            ad = {"float64": PIC_F64, "float32": PIC_F32}[str(np.dtype(accum_dtype))]
-        self.cfg = PicConfig(int(N), int(Ng), int(num_envs), float(L), float(n0), float(dt), float(gamma), pd, ad,
-                             {"CIC": PIC_CIC, "TSC": PIC_TSC}[interpol], int(device_id), int(blocks_per_env),
-                             int(env_index_base))
+        # LDS mesh accumulator (include/picstep.h PIC_ACC_*).  None: the library's choice -- the packed word for
+        # float32 CIC (one integer LDS atomic per deposit), 64-bit fixed point otherwise; both are integer sums, so
+        # a step is bitwise reproducible.  "float64" = float64 running sums (ds_add_f64), float64 particles only.
+        key = accum_dtype if accum_dtype is None else str(accum_dtype)
+        if key not in ACCUMULATORS:
+            raise ValueError(f"accum_dtype must be one of {sorted(k for k in ACCUMULATORS if k)} or None, not {accum_dtype!r}")
+        pkey = position_dtype if position_dtype is None else str(position_dtype)
+        if pkey not in POSITION_FORMATS:
+            raise ValueError(f"position_dtype must be 'float', 'fixed32' or None, not {position_dtype!r}")
+        self.cfg = PicConfig(int(N), int(Ng), int(num_envs), float(L), float(n0), float(dt), float(gamma), pd,
+                             ACCUMULATORS[key], {"CIC": PIC_CIC, "TSC": PIC_TSC}[interpol], int(device_id),
+                             int(blocks_per_env), int(env_index_base), POSITION_FORMATS[pkey])
+        self.fixed_positions = POSITION_FORMATS[pkey] == PIC_POS_FIXED32
         self.N, self.Ng, self.num_envs = int(N), int(Ng), int(num_envs)
         self.dtype = np.dtype(particle_dtype)
         self._h = C.c_void_p()
@@ -190,6 +201,10 @@ class Handle:
 
     def refresh(self):
         self._chk(self.lib.pic_refresh(self._h))
+
+    def invalidate(self):
+        """Call after writing x / v through the device views (or call refresh())."""
+        self._chk(self.lib.pic_invalidate(self._h))
 
     def step(self, E_ext=None, nsteps=1):
         if E_ext is None:

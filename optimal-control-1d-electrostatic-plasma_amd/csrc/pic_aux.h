@@ -5,11 +5,31 @@
 
 namespace {
 
+// position formats <-> length units
+template <typename P>
+__device__ __forceinline__ double pos_to_length(typename P::X q, double L) {
+  if constexpr (P::kFixed) return (double)q * (L * 2.3283064365386963e-10);     // u L / 2^32
+  else return (double)q;
+}
+
+template <typename P>
+__device__ __forceinline__ typename P::X pos_from_length(double xs, double L, unsigned& bad) {
+  if constexpr (P::kFixed) {
+    double r = xs - floor(xs / L) * L;                 // np.mod for any finite xs
+    if (!(r >= 0.0 && r < L)) { if (!(r == L)) bad += 1u; r = 0.0; }
+    return (unsigned)((unsigned long long)rint(r / L * 4294967296.0) & 0xFFFFFFFFull);
+  } else {
+    return (typename P::X)xs;
+  }
+}
+
 // PIC.E (pic.py:120) and the CIC bookkeeping attributes (pic.py:104-107), on demand.
-template <typename T, int SHAPE>
-__global__ __launch_bounds__(BLOCK) void gather_E_kernel(const T* __restrict__ x, const double* __restrict__ E_mesh,
-                                                         T* __restrict__ E_out, long long N, long long ld, int Ng,
-                                                         double Ld, double dxd) {
+template <typename P, int SHAPE>
+__global__ __launch_bounds__(BLOCK) void gather_E_kernel(const typename P::X* __restrict__ x,
+                                                         const double* __restrict__ E_mesh,
+                                                         typename P::W* __restrict__ E_out, long long N, long long ld,
+                                                         int Ng, double Ld, double dxd) {
+  using T = typename P::W;
   constexpr int OFF = (SHAPE == PIC_TSC) ? 1 : 0;
   extern __shared__ __align__(16) unsigned char smem_raw[];
   T* Es = reinterpret_cast<T*>(smem_raw);
@@ -20,12 +40,13 @@ __global__ __launch_bounds__(BLOCK) void gather_E_kernel(const T* __restrict__ x
     Es[i] = (T)E_mesh[(size_t)env * Ng + node];
   }
   __syncthreads();
-  const T L = (T)Ld, dx = (T)dxd;
+  const Consts<P> k(Ld, dxd, Ng);
   for (long long i = (long long)blockIdx.x * BLOCK + threadIdx.x; i < N; i += (long long)gridDim.x * BLOCK) {
-    T w[3], xw;
+    T w[3];
+    typename P::X xw;
     int j;
-    unsigned bad = 0;
-    locate<T, SHAPE>(x[(size_t)env * ld + i], L, dx, T(1) / dx, Ng, xw, j, w, bad);
+    unsigned frac, bad = 0;
+    locate<P, SHAPE>(x[(size_t)env * ld + i], k, xw, j, w, frac, bad);
     E_out[(size_t)env * N + i] = gather_field<T, SHAPE>(Es, j, w);
   }
 }
@@ -33,19 +54,21 @@ __global__ __launch_bounds__(BLOCK) void gather_E_kernel(const T* __restrict__ x
 // Shape-function bookkeeping of every particle: mesh indices and weights as CIC / TSC return them
 // (interpolate.py:8-14: l = floor(x/dx), r = (l+1) mod Ng;  interpolate.py:26-36: m = floor(x/dx), l = (m-1) mod Ng,
 // r = (m+1) mod Ng).  x: [env][ld]; idx, w: [env][3][N], rows l, r, (unused) for CIC and l, m, r for TSC.
-template <typename T, int SHAPE>
-__global__ __launch_bounds__(BLOCK) void shape_query_kernel(const T* __restrict__ x, long long N, long long ld, int Ng,
-                                                            double Ld, double dxd, long long* __restrict__ idx,
-                                                            double* __restrict__ w_out) {
-  const T L = (T)Ld, dx = (T)dxd;
+template <typename P, int SHAPE>
+__global__ __launch_bounds__(BLOCK) void shape_query_kernel(const typename P::X* __restrict__ x, long long N,
+                                                            long long ld, int Ng, double Ld, double dxd,
+                                                            long long* __restrict__ idx, double* __restrict__ w_out) {
+  using T = typename P::W;
+  const Consts<P> k(Ld, dxd, Ng);
   const int env = blockIdx.y;
   long long* je = idx + (size_t)env * 3 * N;
   double* we = w_out + (size_t)env * 3 * N;
   for (long long i = (long long)blockIdx.x * BLOCK + threadIdx.x; i < N; i += (long long)gridDim.x * BLOCK) {
-    T w[3], xw;
+    T w[3];
+    typename P::X xw;
     int j;
-    unsigned bad = 0;
-    locate<T, SHAPE>(x[(size_t)env * ld + i], L, dx, T(1) / dx, Ng, xw, j, w, bad);
+    unsigned frac, bad = 0;
+    locate<P, SHAPE>(x[(size_t)env * ld + i], k, xw, j, w, frac, bad);
     if (SHAPE == PIC_CIC) {
       je[i] = j;
       je[N + i] = (j + 1 == Ng) ? 0 : j + 1;
@@ -58,6 +81,31 @@ __global__ __launch_bounds__(BLOCK) void shape_query_kernel(const T* __restrict_
     we[i] = (double)w[0];
     we[N + i] = (double)w[1];
     we[2 * N + i] = (double)w[2];
+  }
+}
+
+// Fixed-point positions at the boundary: callers hand over and receive positions as floats of the particle dtype.
+// in: dense [env][N] floats -> padded [env][ld] position units; out: the reverse (a value that rounds up to L
+// as a float is returned as 0, its periodic image).
+template <typename P, typename F>
+__global__ __launch_bounds__(BLOCK) void positions_in_kernel(const F* __restrict__ src, typename P::X* __restrict__ dst,
+                                                             long long N, long long ld, double L,
+                                                             unsigned long long* __restrict__ bad_count) {
+  const int env = blockIdx.y;
+  unsigned bad = 0;
+  for (long long i = (long long)blockIdx.x * BLOCK + threadIdx.x; i < N; i += (long long)gridDim.x * BLOCK)
+    dst[(size_t)env * ld + i] = pos_from_length<P>((double)src[(size_t)env * N + i], L, bad);
+  if (bad) atomicAdd(bad_count, (unsigned long long)bad);
+}
+
+template <typename P, typename F>
+__global__ __launch_bounds__(BLOCK) void positions_out_kernel(const typename P::X* __restrict__ src, F* __restrict__ dst,
+                                                              long long N, long long ld, double L) {
+  const int env = blockIdx.y;
+  for (long long i = (long long)blockIdx.x * BLOCK + threadIdx.x; i < N; i += (long long)gridDim.x * BLOCK) {
+    F f = (F)pos_to_length<P>(src[(size_t)env * ld + i], L);
+    if (f >= (F)L) f = F(0);
+    dst[(size_t)env * N + i] = f;
   }
 }
 
@@ -141,8 +189,9 @@ __device__ __forceinline__ double u01(uint32_t a, uint32_t b) {       // 53 rand
 // particles from N(0,1) then the beam from N(v0, sigma) (dist.py:151-189, same ordering as high_indx).
 // Velocities are truncated to [-10, 10] like the reference's uniform proposal; then v *= 1 + A sin(2 pi
 // n_mode x / L) (src/env/pic.py:68).
-template <typename T>
-__global__ __launch_bounds__(BLOCK) void sample_kernel(T* __restrict__ x, T* __restrict__ v, long long N, long long ld,
+template <typename P>
+__global__ __launch_bounds__(BLOCK) void sample_kernel(typename P::X* __restrict__ x, typename P::V* __restrict__ v,
+                                                       long long N, long long ld,
                                                        int kind, double a, double v0, double sigma, double A,
                                                        int n_mode, double L, unsigned long long seed, int env_base) {
   const int env = blockIdx.y;
@@ -167,8 +216,12 @@ __global__ __launch_bounds__(BLOCK) void sample_kernel(T* __restrict__ x, T* __r
       ua = u01(d[2], d[3]);                        // rejected (outside the proposal's support): redraw
     }
     vs *= 1.0 + A * sin(2.0 * 3.14159265358979323846 * n_mode * xs / L);
-    x[(size_t)env * ld + i] = (T)xs;
-    v[(size_t)env * ld + i] = (T)vs;
+    unsigned bad = 0;
+    if constexpr (!P::kFixed) {       // the float32 image of a value just below L may be L itself: its periodic image is 0
+      if ((double)(typename P::X)xs >= L) xs = 0.0;
+    }
+    x[(size_t)env * ld + i] = pos_from_length<P>(xs, L, bad);
+    v[(size_t)env * ld + i] = (typename P::V)vs;
   }
 }
 
@@ -185,15 +238,16 @@ __device__ __forceinline__ int hist_bin(double val, double lo, double hi, double
 }
 
 // Phase-space histogram of the KL diagnostic (src/control/objective.py:8-14): counts[env][ix][iv].
-template <typename T>
-__global__ __launch_bounds__(BLOCK) void phase_hist_kernel(const T* __restrict__ x, const T* __restrict__ v,
+template <typename P>
+__global__ __launch_bounds__(BLOCK) void phase_hist_kernel(const typename P::X* __restrict__ x,
+                                                           const typename P::V* __restrict__ v,
                                                            unsigned* __restrict__ counts, long long N, long long ld,
                                                            int nb, double L, double vmin, double vmax) {
   const int env = blockIdx.y;
   const double sx = (L - 0.0) / nb, sv = (vmax - vmin) / nb;      // np.linspace step = (stop - start) / div
   unsigned* c = counts + (size_t)env * nb * nb;
   for (long long i = (long long)blockIdx.x * BLOCK + threadIdx.x; i < N; i += (long long)gridDim.x * BLOCK) {
-    const int ix = hist_bin((double)x[(size_t)env * ld + i], 0.0, L, sx, nb);
+    const int ix = hist_bin(pos_to_length<P>(x[(size_t)env * ld + i], L), 0.0, L, sx, nb);
     const int iv = hist_bin((double)v[(size_t)env * ld + i], vmin, vmax, sv, nb);
     if (ix >= 0 && iv >= 0) atomicAdd(&c[(size_t)ix * nb + iv], 1u);
   }
@@ -203,17 +257,13 @@ __global__ __launch_bounds__(BLOCK) void phase_hist_kernel(const T* __restrict__
 // per lane, same grid -- what a sweep would take if it did no arithmetic at all.
 __global__ __launch_bounds__(BLOCK) void stream_probe_kernel(double2* __restrict__ a, double2* __restrict__ b,
                                                              long long n2, long long chunk2, double scale,
-                                                             int reverse, int work) {
+                                                             int reverse) {
   const long long bid = reverse ? (long long)gridDim.x - 1 - blockIdx.x : blockIdx.x;
   long long begin = bid * chunk2;
   long long end = begin + chunk2 < n2 ? begin + chunk2 : n2;
   for (long long i = begin + threadIdx.x; i < end; i += BLOCK) {
     double2 u = a[i], w = b[i];
     u.x *= scale; u.y *= scale; w.x *= scale; w.y *= scale;
-    for (int k = 0; k < work; ++k) {   // experiment: dependent fp64 work between the load and the store
-      u.x = fma(u.x, scale, w.x * 1e-300); w.x = fma(w.x, scale, u.y * 1e-300);
-      u.y = fma(u.y, scale, w.y * 1e-300); w.y = fma(w.y, scale, u.x * 1e-300);
-    }
     a[i] = u;
     b[i] = w;
   }

@@ -1,6 +1,7 @@
 // pic_device.h -- launch constants, kernel argument blocks and the per-particle device helpers of picstep.hip:
-// periodic wrap, division by dx, cell location and shape weights, LDS gather / deposit, wave and block scans.
-// Included by picstep.hip only (one translation unit; everything lives in its anonymous namespace).
+// particle formats, periodic wrap, division by dx, cell location and shape weights, LDS gather / deposit,
+// fixed-point conversion, wave and block scans.  Included by picstep.hip only (one translation unit; everything
+// lives in its anonymous namespace).
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -12,20 +13,22 @@
 
 namespace {
 
-#ifndef PIC_BLOCK
-#define PIC_BLOCK 512               // sweep workgroup size: 512 beats 256 by 2.7 % and 128 by 11 % at config 2
-#endif
-constexpr int BLOCK = PIC_BLOCK;    // 8 waves of 64
+constexpr int BLOCK = 512;          // sweep workgroup: 8 waves of 64 (512 beat 256 by 2.7 % and 128 by 11 % at config 2)
 constexpr int WAVES = BLOCK / 64;
 
 enum Stage : int {
   ST_A = 0,        // drift(c) from x,v ; deposit ; nothing stored
   ST_B = 1,        // recompute q1 = x + (c_prev v) dt ; gather ; kick ; drift ; deposit ; store
   ST_C = 2,        // gather ; kick ; drift ; deposit ; store
-  ST_D = 3,        // as C, then wrap, KE ; store wrapped x
-  ST_REFRESH = 4,  // wrap x ; deposit ; KE ; store wrapped x            (pic.py:93-112 on reset)
-  ST_PROBE = 5     // deposit positions of a scratch array, nothing stored (util.py:73-116 callers)
+  ST_D = 3,        // as C, then wrap, KE ; store wrapped x ; deposit the next step's q1 as well
+  ST_REFRESH = 4,  // wrap x ; deposit ; KE ; store wrapped x ; deposit the next step's q1   (pic.py:93-112 on reset)
+  ST_PROBE = 5     // deposit positions of a scratch array, nothing stored             (util.py:73-116 callers)
 };
+
+// Mesh accumulators that cross a kernel boundary: per environment and node the sum of shape weights as a 64-bit
+// integer in units of 2^-fg.  Integer sums do not depend on the order of the adds, so the result of a sweep is
+// the same whatever the launch geometry and however the adds of different workgroups interleave.
+using acc_t = long long;
 
 struct SweepArgs {
   long long N;        // particles per env
@@ -35,20 +38,55 @@ struct SweepArgs {
   int nblk;           // workgroups per env
   int R;              // LDS mesh replicas per workgroup (1, 2 or 4)
   int reverse;        // walk environments and chunks from the far end (alternates sweep to sweep)
-  int env0;           // first environment of this launch (launches may cover a group of environments)
-  double L, dx, rdx, dt;   // rdx = 1/dx (for float particles: 1/(float)dx)
+  int fg;             // fractional bits of the fixed-point accumulators
+  double magic;       // 1.5 * 2^(52 - fg): (w + magic) holds round(w 2^fg) in its low mantissa bits
+  double L, dx, rdx, dt;   // rdx = 1/dx (float particles: 1/(float)dx)
   double c_prev, c_cur, d_cur, c_next;
   double scale, n0;   // density scale n0 L / N / dx and mean density, for the in-prologue field solve
+  double to_units;    // 2^32 / L: fixed-point position units per length (PosU32)
 };
 
 struct SolveArgs {
   long long N;
   int Ng;
   int nblk;
+  int fg;
   double L, dx, n0;
-  int env0;            // first environment of this launch
   double scale;        // n0 * L / N / dx, evaluated left to right as interpolate.py:18
   double N_over_L;
+};
+
+// ---------------------------------------------------------------------------------------------
+// Particle formats.  X / V: storage types of position and velocity; W: type locate, the shape weights,
+// the gather and the kick are evaluated in; XV / VV: the 16-byte vectors a lane streams.
+//   PosF64  the parity format: everything float64, the reference's arithmetic operand by operand
+//   PosF32  float32 positions and velocities
+//   PosU32  positions as 32-bit fixed point x = u L / 2^32 (wrap = integer overflow, cell = high word of
+//           u Ng, weight = low word), float32 velocities: uniform 1.2e-8 resolution on a 50-long box instead
+//           of float32's 3.8e-6 near x = L (profiles/fp32_error_model.md)
+// ---------------------------------------------------------------------------------------------
+typedef double pic_v2d __attribute__((ext_vector_type(2)));
+typedef float pic_v4f __attribute__((ext_vector_type(4)));
+typedef unsigned pic_v4u __attribute__((ext_vector_type(4)));
+
+struct PosF64 { using X = double;   using V = double; using W = double; using XV = pic_v2d; using VV = pic_v2d; static constexpr int VEC = 2; static constexpr bool kFixed = false; };
+struct PosF32 { using X = float;    using V = float;  using W = float;  using XV = pic_v4f; using VV = pic_v4f; static constexpr int VEC = 4; static constexpr bool kFixed = false; };
+struct PosU32 { using X = unsigned; using V = float;  using W = float;  using XV = pic_v4u; using VV = pic_v4f; static constexpr int VEC = 4; static constexpr bool kFixed = true; };
+
+// loop-invariant scalars of a sweep in the format's arithmetic type
+template <typename P>
+struct Consts {
+  typename P::W L, dx, rdx, dt, c_prev, c_cur, d_cur, c_next;
+  float to_units;
+  double magic;
+  int Ng;
+  __device__ explicit Consts(const SweepArgs& a)
+      : L((typename P::W)a.L), dx((typename P::W)a.dx), rdx((typename P::W)a.rdx), dt((typename P::W)a.dt),
+        c_prev((typename P::W)a.c_prev), c_cur((typename P::W)a.c_cur), d_cur((typename P::W)a.d_cur),
+        c_next((typename P::W)a.c_next), to_units((float)a.to_units), magic(a.magic), Ng(a.Ng) {}
+  __device__ Consts(double L_, double dx_, int Ng_)
+      : L((typename P::W)L_), dx((typename P::W)dx_), rdx((typename P::W)1 / (typename P::W)dx_), dt(0), c_prev(0),
+        c_cur(0), d_cur(0), c_next(0), to_units((float)(4294967296.0 / L_)), magic(0), Ng(Ng_) {}
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -71,20 +109,6 @@ __device__ __noinline__ T wrap_periodic_far(T q, T L) {   // |q| beyond one box 
 
 template <typename T>
 __device__ __forceinline__ T wrap_periodic(T q, T L) {
-#ifdef PIC_EXP_BRANCHY_WRAP
-  T r;
-  if (q >= T(0) && q < L) {
-    r = q;
-  } else if (q >= L && q < L + L) {
-    r = q - L;
-  } else if (q < T(0) && q >= -L) {
-    r = q + L;
-    if (r >= L) r = T(0);
-  } else {
-    r = wrap_periodic_far(q, L);
-  }
-  return r;
-#else
   // the three near ranges as selects (a particle moves a small fraction of L per sub-stage)
   T up = q + L;                       // q in [-L, 0)
   up = (up >= L) ? T(0) : up;         // tiny negative q: q + L rounds to L, the second mod gives 0
@@ -92,7 +116,6 @@ __device__ __forceinline__ T wrap_periodic(T q, T L) {
   r = (q >= L) ? q - L : r;           // q in [L, 2L): exact (Sterbenz)
   if (__builtin_expect(!(q >= -L && q < L + L), 0)) r = wrap_periodic_far(q, L);
   return r;
-#endif
 }
 
 // a / dx for the loop-invariant divisor dx, with rdx = 1/dx rounded once on the host: one Newton
@@ -103,43 +126,75 @@ __device__ __forceinline__ T wrap_periodic(T q, T L) {
 // which made sweep D division-bound.  tests/ check it bit for bit against true division.
 template <typename T>
 __device__ __forceinline__ T div_dx(T a, T dx, T rdx) {
-#if defined(PIC_EXP_TRUEDIV)
-  return a / dx;
-#elif defined(PIC_EXP_RCPDIV)
-  return a * rdx;
-#else
   T q0 = a * rdx;
   T rem = fma(-q0, dx, a);
   return fma(rem, rdx, q0);
-#endif
 }
 
 // Cell index and shape-function weights at position q.  j is the LDS index of the leftmost
 // touched node (mesh node + OFF, OFF = 1 for TSC so that node -1 has a slot).
 //   CIC (interpolate.py:6-13): jl = floor(xw/dx); wl = ((jl+1) dx - xw)/dx; wr = (xw - jl dx)/dx
 //   TSC (interpolate.py:24-34): d = (xw - jm dx)/dx; wl = .5(1.5-d)^2; wm = .75-(d-1)^2; wr = .5(d-.5)^2
-template <typename T, int SHAPE>
-__device__ __forceinline__ void locate(T q, T L, T dx, T rdx, int Ng, T& xw, int& j, T (&w)[3], unsigned& bad) {
-  xw = wrap_periodic(q, L);
-  if (!(xw >= T(0) && xw < L)) {   // NaN / inf position: count it, park it on node 0, never index with it
-    bad += 1u;
-    xw = T(0);
-  }
-  T jf = floor(div_dx(xw, dx, rdx));
-  j = (int)jf;
-  // j == Ng happens when xw/dx rounds up to Ng (undefined in the reference: bincount grows a bin and
-  // solve.py:32 raises); it is folded to node 0 with the weights of the unfolded index.
-  if ((unsigned)j >= (unsigned)Ng) j = 0;
-  if (SHAPE == PIC_CIC) {
-    w[0] = div_dx((jf + T(1)) * dx - xw, dx, rdx);
-    w[1] = div_dx(xw - jf * dx, dx, rdx);
-    w[2] = T(0);
+// xw: the wrapped position (what sweep D stores).  frac: PosU32 only, the position inside the cell in
+// units of 2^-32 cell (the right CIC weight, exactly).
+template <typename P, int SHAPE>
+__device__ __forceinline__ void locate(typename P::X q, const Consts<P>& k, typename P::X& xw, int& j,
+                                       typename P::W (&w)[3], unsigned& frac, unsigned& bad) {
+  using T = typename P::W;
+  if constexpr (P::kFixed) {
+    xw = q;                                            // every 32-bit pattern is a position in [0, L)
+    j = (int)__umulhi(q, (unsigned)k.Ng);              // floor(u Ng / 2^32)
+    frac = q * (unsigned)k.Ng;                         // (u Ng) mod 2^32
+    const T d = (T)frac * T(2.3283064365386963e-10);   // 2^-32
+    if (SHAPE == PIC_CIC) {
+      w[1] = d;
+      w[0] = T(1) - d;
+      w[2] = T(0);
+    } else {
+      T a = T(1.5) - d, b = d - T(1), c = d - T(0.5);
+      w[0] = T(0.5) * (a * a);
+      w[1] = T(0.75) - b * b;
+      w[2] = T(0.5) * (c * c);
+    }
   } else {
-    T d = div_dx(xw - jf * dx, dx, rdx);
-    T a = T(1.5) - d, b = d - T(1), c = d - T(0.5);
-    w[0] = T(0.5) * (a * a);
-    w[1] = T(0.75) - b * b;
-    w[2] = T(0.5) * (c * c);
+    frac = 0u;
+    xw = wrap_periodic(q, k.L);
+    if (!(xw >= T(0) && xw < k.L)) {   // NaN / inf position: count it, park it on node 0, never index with it
+      bad += 1u;
+      xw = T(0);
+    }
+    T jf = floor(div_dx(xw, k.dx, k.rdx));
+    j = (int)jf;
+    // j == Ng happens when xw/dx rounds up to Ng (undefined in the reference: bincount grows a bin and
+    // solve.py:32 raises); it is folded to node 0 with the weights of the unfolded index.
+    if ((unsigned)j >= (unsigned)k.Ng) j = 0;
+    if (SHAPE == PIC_CIC) {
+      w[0] = div_dx((jf + T(1)) * k.dx - xw, k.dx, k.rdx);
+      w[1] = div_dx(xw - jf * k.dx, k.dx, k.rdx);
+      w[2] = T(0);
+    } else {
+      T d = div_dx(xw - jf * k.dx, k.dx, k.rdx);
+      T a = T(1.5) - d, b = d - T(1), c = d - T(0.5);
+      w[0] = T(0.5) * (a * a);
+      w[1] = T(0.75) - b * b;
+      w[2] = T(0.5) * (c * c);
+    }
+  }
+}
+
+// q + (c p) dt  (integration.py:42).  PosU32: the displacement is rounded to position units and added modulo
+// 2^32, which is the periodic wrap; a displacement of half a box or more per sub-stage cannot be represented
+// (and is far outside any CFL-limited step): counted as a bad position.
+template <typename P>
+__device__ __forceinline__ typename P::X drift(typename P::X q, typename P::V p, typename P::W c, const Consts<P>& k,
+                                               unsigned& bad) {
+  using T = typename P::W;
+  if constexpr (P::kFixed) {
+    const float d = ((c * (T)p) * k.dt) * k.to_units;
+    if (!(fabsf(d) < 2147483648.0f)) bad += 1u;
+    return q + (unsigned)__float2int_rn(d);
+  } else {
+    return q + (c * (T)p) * k.dt;
   }
 }
 
@@ -150,49 +205,52 @@ __device__ __forceinline__ T gather_field(const T* __restrict__ Es, int j, const
   return e;
 }
 
-// Packed fixed-point LDS accumulator for float32 particles (accum_dtype PIC_FIXED, CIC only).  A particle in
-// cell j adds w_l = 1 - w_r to node j and w_r to node j+1, so per cell the pair (count, sum of w_r) carries the
-// whole deposit: n_j = count_j - S_j + S_{j-1}.  Both live in one 64-bit word -- count in the top 20 bits,
-// S in 2^-24 units below -- and one native ds_add_u64 replaces two ds_add_f64 (sweep D of config 3:
-// 0.458 -> 0.395 ms; integer sums are also order-independent).  2^-24 is below the rounding of a float32
-// weight; a workgroup handles fewer than 2^20 particles (pic_create sees to it), so neither field overflows.
-using fix_t = unsigned long long;
+// ---------------------------------------------------------------------------------------------
+// LDS accumulators (template parameter A of the sweeps)
+//   acc_t   round(w 2^fg) per weight, integer ds_add_u64: the default.  Sums are exact integers, hence
+//           independent of the order in which the waves' atomics land: a step is bitwise reproducible.
+//           Rounding a weight to 2^-fg (fg = 38..50 by particle count) is below what one float64 add of
+//           the running sum rounds away.
+//   double  ds_add_f64 (accum_dtype PIC_F64): float64 running sums, order-dependent in the last bits.
+//   fix_t   packed (count, sum of w_r) per cell in one word (accum_dtype PIC_FIXED, single-precision CIC):
+//           a particle in cell j adds w_l = 1 - w_r to node j and w_r to node j+1, so per cell the pair
+//           carries the whole deposit, n_j = count_j - S_j + S_{j-1}: ONE ds_add_u64 per particle instead of
+//           two.  count in the top 20 bits, S in 2^-24 units below; a workgroup handles fewer than 2^20
+//           particles (pic_create sees to it), so neither field overflows.
+// ---------------------------------------------------------------------------------------------
+struct fix_t { unsigned long long v; };
 constexpr int FX_FRAC = 24;
 constexpr int FX_LOW = 44;
 
-template <typename A, typename T, int SHAPE>
-__device__ __forceinline__ void deposit(A* __restrict__ acc, int j, const T (&w)[3]) {
-#ifdef PIC_EXP_NODEPOSIT   // timing experiment only: keep the operands alive, drop the LDS atomics
-  asm volatile("" ::"v"(w[0]), "v"(w[1]), "v"(j));
-  (void)acc;
-#else
+__device__ __forceinline__ acc_t to_fixed(double w, double magic) {
+  // w + magic has ulp 2^-fg, so its mantissa differs from magic's by round-to-nearest-even(w 2^fg)
+  return __double_as_longlong(w + magic) - __double_as_longlong(magic);
+}
+
+template <typename A, typename P, int SHAPE>
+__device__ __forceinline__ void deposit(A* __restrict__ acc, int j, const typename P::W (&w)[3], unsigned frac,
+                                        double magic) {
   if constexpr (std::is_same<A, fix_t>::value) {
-    // one integer atomic per particle into its own cell: count in the high field, w_r in the low one
     static_assert(SHAPE == PIC_CIC, "the packed accumulator is CIC only");
-    const float wr = fminf(fmaxf((float)w[1], 0.0f), 1.0f);
-    atomicAdd(&acc[j], (1ull << FX_LOW) + (unsigned long long)(unsigned)(wr * (float)(1u << FX_FRAC) + 0.5f));
+    unsigned long long lo;
+    if constexpr (P::kFixed) {
+      lo = (frac >> 8) + ((frac >> 7) & 1u);                        // w_r rounded to 2^-24
+    } else {
+      const float wr = fminf(fmaxf((float)w[1], 0.0f), 1.0f);
+      lo = (unsigned long long)(unsigned)(wr * (float)(1u << FX_FRAC) + 0.5f);
+    }
+    atomicAdd(reinterpret_cast<unsigned long long*>(acc) + j, (1ull << FX_LOW) + lo);
+  } else if constexpr (std::is_same<A, acc_t>::value) {
+    unsigned long long* a = reinterpret_cast<unsigned long long*>(acc);
+    atomicAdd(a + j, (unsigned long long)to_fixed((double)w[0], magic));
+    atomicAdd(a + j + 1, (unsigned long long)to_fixed((double)w[1], magic));
+    if (SHAPE == PIC_TSC) atomicAdd(a + j + 2, (unsigned long long)to_fixed((double)w[2], magic));
   } else {
     atomicAdd(&acc[j], (A)w[0]);
     atomicAdd(&acc[j + 1], (A)w[1]);
     if (SHAPE == PIC_TSC) atomicAdd(&acc[j + 2], (A)w[2]);
   }
-#endif
 }
-
-#ifndef PIC_PIPE
-#define PIC_PIPE 0      // tiles prefetched ahead of the one being pushed (experiment; the compiler sinks them)
-#endif
-#ifndef PIC_TILES
-#define PIC_TILES 1     // 16-B tiles per lane per loop iteration
-#endif
-#define PIC_LOAD(p) (*(p))
-#define PIC_STORE(v, p) (*(p) = (v))
-
-template <typename T> struct VecOf;
-typedef double pic_v2d __attribute__((ext_vector_type(2)));   // 16 B per lane either way
-typedef float pic_v4f __attribute__((ext_vector_type(4)));
-template <> struct VecOf<double> { using type = pic_v2d; static constexpr int n = 2; };
-template <> struct VecOf<float> { using type = pic_v4f; static constexpr int n = 4; };
 
 __device__ __forceinline__ double wave_sum(double v) {
   for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
@@ -235,6 +293,34 @@ __device__ __forceinline__ double block_sum(double v, double* ws) {
   for (int i = 0; i < NW; ++i) s += ws[i];
   __syncthreads();
   return s;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Periodic Poisson solve of one environment by a workgroup of NW waves, in LDS.
+// Replaces Gaussian_Elimination_Periodic + the dense grad matvec (src/env/solve.py:27-53, src/env/util.py:99-103,
+// pic.py:116-117).  With G_{j+1/2} = (phi_{j+1}-phi_j)/dx the 3-point periodic Poisson equation reads
+// G_{j+1/2} - G_{j-1/2} = b_j dx, so G = cumsum(b) dx - mean and E_j = -(phi_{j+1}-phi_{j-1})/(2dx)
+// = -(G_{j+1/2} + G_{j-1/2})/2.  In: sb[0..Ng) = b = n - n0.  Out: sb = G_{j+1/2} (mean NOT removed), returns mean(G).
+// Ends with a barrier.
+// ---------------------------------------------------------------------------------------------
+template <int NW>
+__device__ __forceinline__ double scan_gradient(double* __restrict__ sb, int Ng, double dx, double* __restrict__ ws) {
+  constexpr int NT = NW * 64;
+  const int tid = threadIdx.x;
+  const int m = (Ng + NT - 1) / NT;
+  const int lo = min(tid * m, Ng), hi = min(lo + m, Ng);
+  double loc = 0.0;
+  for (int j = lo; j < hi; ++j) loc += sb[j];
+  double tot;
+  double run = block_excl_scan<NW>(loc, ws, tot);
+  loc = 0.0;
+  for (int j = lo; j < hi; ++j) {
+    run += sb[j];
+    const double g = run * dx;
+    sb[j] = g;
+    loc += g;
+  }
+  return block_sum<NW>(loc, ws) / (double)Ng;     // syncs: sb holds G everywhere
 }
 
 }  // namespace

@@ -7,35 +7,30 @@
 //
 //   [sweep A: q1 = x + (c1 v) dt ; deposit(q1)]   -- normally NOT run: the previous sweep D (or the
 //                                                    reset sweep) has already deposited this q1
-//   solve   : E = field(deposit of q1) + E_ext
-//   sweep B : p1 = v + (d1 (-E(q1))) dt ; q2 = q1 + (c2 p1) dt ; deposit(q2) ; store q2, p1
-//   solve
-//   sweep C : p2 = p1 + (d2 (-E(q2))) dt ; q3 = q2 + (c3 p2) dt ; deposit(q3) ; store
-//   solve
-//   sweep D : p3 = p2 + (d3 (-E(q3))) dt ; q4 = q3 + (c4 p3) dt ; x' = mod(q4, L) ; deposit(x') ;
-//             KE partials ; store x', p3 ; deposit(next q1 = x' + (c1 p3) dt) into a second mesh
+//   sweep B : E = field(deposit of q1) + E_ext ; p1 = v + (d1 (-E(q1))) dt ; q2 = q1 + (c2 p1) dt ; deposit(q2)
+//   sweep C : E = field(deposit of q2) + E_ext ; p2 = p1 + (d2 (-E(q2))) dt ; q3 = q2 + (c3 p2) dt ; deposit(q3)
+//   sweep D : E = field(deposit of q3) + E_ext ; p3 = p2 + (d3 (-E(q3))) dt ; q4 = q3 + (c4 p3) dt ;
+//             x' = mod(q4, L) ; deposit(x') ; KE partials ; store x', p3 ;
+//             deposit(next q1 = x' + (c1 p3) dt) into a second mesh
 //   solve   : n, E_mesh (no E_ext), phi, KE, PE, PE_reward        (pic.py:145-146, util.py:119-147)
 //
-// 7 launches for a lone step, 6 per step inside a multi-step call (the final solve shares a launch with the
-// next step's first one), 4 for small problems (force solves folded into the sweep prologues); 3 read+write
-// passes over the particles per step (96 B per particle-step in fp64).
+// 4 launches and 3 read+write passes over the particles per step (96 B per particle-step in fp64).  Every
+// sweep workgroup solves the field it gathers from in its own prologue (pic_sweep.h: prologue_field), from
+// the accumulator row the previous sweep filled.
 //
 // Arithmetic inside a sub-stage keeps the reference's operand order and is compiled with
 // -ffp-contract=off so that fp64 results track NumPy to rounding (tests/ hold the bounds).
 //
-// Deposit: every workgroup owns LDS copies of its environment's mesh (one per wave, `R` copies, two
-// sets in sweep D), accumulates with LDS atomics (ds_add_f64; for float32 particles one packed ds_add_u64
-// per deposit, pic_device.h; ds_add_f32 is selectable but measured ~4x slower), then stores its partial mesh
-// as one row of a slab [env][block][Ng] with plain
-// coalesced stores.  The field-solve kernel sums the rows in a fixed order (no global atomics, no
-// memset between sweeps), scales to a density and solves the periodic Poisson problem with two prefix
-// scans.
+// Deposit: every workgroup owns LDS copies of its environment's mesh (one per wave pair, two sets in sweep D)
+// and accumulates with integer LDS atomics (weights as 2^-fg fixed point, or one packed word per particle for
+// single-precision CIC; pic_device.h), then adds its partial mesh to the environment's row [env][Ng] of a
+// global 64-bit fixed-point accumulator with memory-side integer atomics.  Integer sums are order-independent:
+// a step is bitwise reproducible and does not depend on the launch geometry.  Accumulator rows rotate through a
+// small ring; a row whose readers are done is cleared by a later sweep (no memset launches).
 //
-// Compile-time switches (all off in the shipped build; results of each in profiles/experiments_r1.md):
-// PIC_EXP_* are timing/diagnostic experiments, PIC_PIPE / PIC_TILES alternative loop forms.
-//
-// Files: pic_device.h (per-particle helpers, scans), pic_sweep.h (push sweeps), pic_solve.h (field solve),
-// pic_aux.h (kernels off the step path); this file holds the handle, the launch schedule and the C ABI.
+// Files: pic_device.h (particle formats, per-particle helpers, scans), pic_sweep.h (push sweeps), pic_solve.h
+// (field solve), pic_aux.h (kernels off the step path); this file holds the handle, the launch schedule and
+// the C ABI.
 
 #include <hip/hip_runtime.h>
 
@@ -60,48 +55,39 @@
 // ---------------------------------------------------------------------------------------------
 // Host side
 // ---------------------------------------------------------------------------------------------
-// one captured environment step (7 kernel nodes), valid for one external-field pointer and start parity
-struct StepGraph {
-  hipGraphExec_t exec = nullptr;
-  const double* ext = nullptr;
-  int parity = 0, parity_out = 0;
-};
+enum Format : int { FMT_F64 = 0, FMT_F32 = 1, FMT_U32 = 2 };     // PosF64 / PosF32 / PosU32
+constexpr int RING = 8;                                          // accumulator rows in rotation
 
 struct pic_handle {
   pic_config cfg{};
+  int fmt = FMT_F64;
+  int acc_kind = PIC_ACC_FIX64;  // resolved accumulator (never PIC_ACC_AUTO)
   int vec = 2;
-  size_t esz = 8;          // particle element size
-  size_t asz = 8;          // LDS accumulator element size
+  size_t esz = 8;          // particle element size (positions and velocities have the same width in every format)
   long long ld = 0;
   long long chunk = 0;
   int nblk = 0;
   int R = 1;
+  int fg = 42;             // fractional bits of the fixed-point accumulators
+  double magic = 0;
   size_t sweep_lds = 0, solve_lds = 0;
   double dx = 0, scale = 0;
   double cs[4]{}, ds[4]{};
   hipStream_t stream = nullptr;       // the stream every call works on (own_stream, or the caller's)
   hipStream_t own_stream = nullptr;   // created by pic_create, destroyed by pic_destroy
-  // Cache-resident schedule: pic_step walks the environments in groups whose particles fit the
-  // Infinity Cache, each group running all its sweeps back to back on one of `wstreams`.
-  std::vector<hipStream_t> wstreams;
-  std::vector<hipEvent_t> join_ev;
-  hipEvent_t fork_ev = nullptr;
-  int group_envs = 0;             // 0 = no grouping (every launch covers all environments)
-  bool group_major = true;        // all nsteps of a group before the next group (else step by step)
   void* x = nullptr;
   void* v = nullptr;
-  void* scratch = nullptr;        // [env][ld] staging (eval_field positions, dense<->padded copies)
-  double* part = nullptr;         // [env][nblk][Ng] deposit of the sweep just run
-  double* part2 = nullptr;        // [env][nblk][Ng] deposit of the NEXT step's q1 (sweeps D / REFRESH)
-  double* part_b = nullptr;       // second buffer for `part` (sweep C writes it while late C workgroups still read `part`)
-  bool fused_solve = false;       // force-evaluation solves in the sweep prologues (4 launches per step)
-  bool pair_solves = true;        // multi-step calls: final solve of step s + first force solve of s+1 in one launch
+  void* scratch = nullptr;        // [env][ld] positions of a probe (eval_field / compute_E)
+  void* stage = nullptr;          // [env][N] float staging: fixed-point positions <-> the caller's floats
+  // accumulator ring: rows [env][Ng] of 64-bit fixed-point weight sums
+  acc_t* ring = nullptr;
+  std::vector<int> clean, dirty;  // rows that are zero / rows whose readers have all been enqueued
+  int q_slot = -1;                // row holding the deposit of the NEXT step's q1 (sweep A is skipped while >= 0)
+  int stage_slot = -1;            // pic_step_stage: row the next stage's field comes from
   int sweep_parity = 0;           // direction of the next push sweep
-  bool use_graph = false;         // replay steps from hipGraphs (launch-bound sizes)
-  std::vector<StepGraph> graphs;
-  bool q1_ready = false;          // part2 matches the stored particles, dt and c1: sweep A can be skipped
+  acc_t* probe_acc = nullptr;     // accumulator row of the probes (their own: a probe never touches step state)
+  double* probe_ext = nullptr;    // device copy of a probe's host E_ext
   double* ke_part = nullptr;      // [env][nblk]
-  double* Ef = nullptr;           // field used by the gathers (E + E_ext)
   double* n = nullptr;
   double* E_mesh = nullptr;
   double* phi = nullptr;
@@ -111,10 +97,10 @@ struct pic_handle {
   double* modes = nullptr;        // [2][env][M] Fourier modes (re, im)
   int act_modes = 0;
   int modes_cap = 0;
-  double* aux_n = nullptr;        // eval_field outputs
+  double* aux_n = nullptr;        // probe outputs
   double* aux_E = nullptr;
   double* aux_pe = nullptr;
-  double* aux_phi = nullptr;      // pic_compute_E / pic_solve_poisson: potential of the probe solve
+  double* aux_phi = nullptr;
   int mid_stage = 0;              // pic_step_stage: force evaluations of the current step already done (0 = between steps)
   double* KE = nullptr;
   double* PE = nullptr;
@@ -161,45 +147,60 @@ void yoshida_coefficients(double (&c)[4], double (&d)[4]) {
   d[2] = w0;
 }
 
-// what a sweep reads its field from and where its deposits go
-struct SweepIO {
-  const double* slab_in = nullptr;   // non-null: solve the field in the prologue from this slab (+ ext)
-  const double* ext = nullptr;
-  double* out = nullptr;             // slab receiving this sweep's deposit
-  double* out2 = nullptr;            // slab receiving the next step's q1 deposit (dual stages)
-};
+// ---- accumulator ring -------------------------------------------------------------------------
+acc_t* ring_row(pic_handle* h, int slot) { return h->ring + (size_t)slot * h->cfg.num_envs * h->cfg.Ng; }
 
-// where a launch goes: stream + the block of environments it covers
-struct Lane {
-  hipStream_t stream;
-  int env0, nenv;
-  int parity;       // direction of this lane's next push sweep
-};
-
-template <typename T, typename A, int SHAPE, int STAGE>
-void launch_sweep_t(pic_handle* h, const Lane& ln, const SweepIO& io, void* x, void* v, const SweepArgs& a) {
-  dim3 grid(h->nblk, ln.nenv);
-  hipLaunchKernelGGL((sweep_kernel<T, A, SHAPE, STAGE>), grid, dim3(BLOCK), h->sweep_lds, ln.stream,
-                     static_cast<T*>(x), static_cast<T*>(v), h->Ef, io.slab_in, io.ext, io.out ? io.out : h->part,
-                     io.out2 ? io.out2 : h->part2, h->ke_part, h->bad, a);
+// a zeroed row for the deposit of the sweep about to be launched
+int ring_take_clean(pic_handle* h) {
+  if (h->clean.empty()) {          // not reached by the step schedule (every sweep clears two retired rows)
+    const int s = h->dirty.front();
+    h->dirty.erase(h->dirty.begin());
+    hipMemsetAsync(ring_row(h, s), 0, (size_t)h->cfg.num_envs * h->cfg.Ng * sizeof(acc_t), h->stream);
+    return s;
+  }
+  const int s = h->clean.back();
+  h->clean.pop_back();
+  return s;
 }
 
-template <typename T, typename A, int SHAPE>
-void launch_sweep_s(pic_handle* h, const Lane& ln, const SweepIO& io, int stage, void* x, void* v, const SweepArgs& a) {
+// the last kernel reading `slot` has been enqueued: any later sweep may clear it
+void ring_retire(pic_handle* h, int slot) {
+  if (slot >= 0) h->dirty.push_back(slot);
+}
+
+template <typename P, typename A, int SHAPE, int STAGE>
+void launch_sweep_t(pic_handle* h, const SweepIO& io, void* x, void* v, const SweepArgs& a) {
+  dim3 grid(h->nblk, h->cfg.num_envs);
+  hipLaunchKernelGGL((sweep_kernel<P, A, SHAPE, STAGE>), grid, dim3(BLOCK), h->sweep_lds, h->stream,
+                     static_cast<typename P::X*>(x), static_cast<typename P::V*>(v), io, a);
+}
+
+template <typename P, typename A, int SHAPE>
+void launch_sweep_s(pic_handle* h, const SweepIO& io, int stage, void* x, void* v, const SweepArgs& a) {
   switch (stage) {
-    case ST_A: launch_sweep_t<T, A, SHAPE, ST_A>(h, ln, io, x, v, a); break;
-    case ST_B: launch_sweep_t<T, A, SHAPE, ST_B>(h, ln, io, x, v, a); break;
-    case ST_C: launch_sweep_t<T, A, SHAPE, ST_C>(h, ln, io, x, v, a); break;
-    case ST_D: launch_sweep_t<T, A, SHAPE, ST_D>(h, ln, io, x, v, a); break;
-    case ST_REFRESH: launch_sweep_t<T, A, SHAPE, ST_REFRESH>(h, ln, io, x, v, a); break;
-    default: launch_sweep_t<T, A, SHAPE, ST_PROBE>(h, ln, io, x, v, a); break;
+    case ST_A: launch_sweep_t<P, A, SHAPE, ST_A>(h, io, x, v, a); break;
+    case ST_B: launch_sweep_t<P, A, SHAPE, ST_B>(h, io, x, v, a); break;
+    case ST_C: launch_sweep_t<P, A, SHAPE, ST_C>(h, io, x, v, a); break;
+    case ST_D: launch_sweep_t<P, A, SHAPE, ST_D>(h, io, x, v, a); break;
+    case ST_REFRESH: launch_sweep_t<P, A, SHAPE, ST_REFRESH>(h, io, x, v, a); break;
+    default: launch_sweep_t<P, A, SHAPE, ST_PROBE>(h, io, x, v, a); break;
   }
 }
 
-template <typename T, typename A>
-void launch_sweep_i(pic_handle* h, const Lane& ln, const SweepIO& io, int stage, void* x, void* v, const SweepArgs& a) {
-  if (h->cfg.interpol == PIC_TSC) launch_sweep_s<T, A, PIC_TSC>(h, ln, io, stage, x, v, a);
-  else launch_sweep_s<T, A, PIC_CIC>(h, ln, io, stage, x, v, a);
+template <typename P>
+void launch_sweep_p(pic_handle* h, const SweepIO& io, int stage, void* x, void* v, const SweepArgs& a) {
+  const bool tsc = h->cfg.interpol == PIC_TSC;
+  if constexpr (std::is_same<P, PosF64>::value) {
+    if (h->acc_kind == PIC_ACC_F64) {
+      if (tsc) launch_sweep_s<P, double, PIC_TSC>(h, io, stage, x, v, a);
+      else launch_sweep_s<P, double, PIC_CIC>(h, io, stage, x, v, a);
+      return;
+    }
+  } else {
+    if (h->acc_kind == PIC_ACC_PACKED) { launch_sweep_s<P, fix_t, PIC_CIC>(h, io, stage, x, v, a); return; }
+  }
+  if (tsc) launch_sweep_s<P, acc_t, PIC_TSC>(h, io, stage, x, v, a);
+  else launch_sweep_s<P, acc_t, PIC_CIC>(h, io, stage, x, v, a);
 }
 
 // Per-launch HIP-event brackets on the handle's stream.  Events come from a pool that is only grown
@@ -222,127 +223,126 @@ void prof_reserve(pic_handle* h, size_t pairs) {
     h->ev.push_back(e);
   }
 }
-void prof_begin(pic_handle* h, hipStream_t st, int kind) {
+void prof_begin(pic_handle* h, int kind) {
   if (!h->prof) return;
   if (h->ev_kind.size() >= 16384) prof_drain(h);
   const size_t i = h->ev_kind.size();
   prof_reserve(h, i + 1);
-  hipEventRecord(h->ev[2 * i], st);
+  hipEventRecord(h->ev[2 * i], h->stream);
   h->ev_kind.push_back(kind);
 }
-void prof_end(pic_handle* h, hipStream_t st) {
+void prof_end(pic_handle* h) {
   if (!h->prof) return;
-  hipEventRecord(h->ev[2 * (h->ev_kind.size() - 1) + 1], st);
+  hipEventRecord(h->ev[2 * (h->ev_kind.size() - 1) + 1], h->stream);
 }
 
-Lane whole(pic_handle* h) { return Lane{h->stream, 0, h->cfg.num_envs, 0}; }
-
-void launch_sweep(pic_handle* h, Lane& ln, int stage, void* x, void* v, double c_prev, double c_cur, double d_cur,
-                  const SweepIO& io = SweepIO()) {
+// One sweep over all environments.  in_slot: ring row the gather field is solved from (gather stages);
+// out / out2: rows (or the probe accumulator) receiving the deposits.  The sweep also clears up to two
+// retired ring rows for later use.
+void launch_sweep(pic_handle* h, int stage, void* x, void* v, double c_prev, double c_cur, double d_cur,
+                  int in_slot, const double* ext, acc_t* out, acc_t* out2) {
   SweepArgs a;
-  a.c_next = h->cs[0];
-  a.env0 = ln.env0;
-  a.scale = h->scale;
-  a.n0 = h->cfg.n0;
   a.N = h->cfg.N; a.ld = h->ld; a.chunk = h->chunk; a.Ng = h->cfg.Ng; a.nblk = h->nblk; a.R = h->R;
-#ifdef PIC_EXP_NOREVERSE
-  a.reverse = 0;
-#else
-  a.reverse = (stage <= ST_D) ? (ln.parity ^= 1) : 0;
-#endif
+  a.reverse = (stage <= ST_D) ? (h->sweep_parity ^= 1) : 0;
+  a.fg = h->fg; a.magic = h->magic;
   a.L = h->cfg.L; a.dx = h->dx; a.dt = h->cfg.dt;
-  a.rdx = h->cfg.particle_dtype == PIC_F64 ? 1.0 / h->dx : (double)(1.0f / (float)h->dx);
-  a.c_prev = c_prev; a.c_cur = c_cur; a.d_cur = d_cur;
-  prof_begin(h, ln.stream, stage <= ST_D ? stage : 5);
-  if (h->cfg.particle_dtype == PIC_F64) launch_sweep_i<double, double>(h, ln, io, stage, x, v, a);
-  else if (h->cfg.accum_dtype == PIC_F64) launch_sweep_i<float, double>(h, ln, io, stage, x, v, a);
-  else if (h->cfg.accum_dtype == PIC_FIXED) launch_sweep_s<float, fix_t, PIC_CIC>(h, ln, io, stage, x, v, a);
-  else launch_sweep_i<float, float>(h, ln, io, stage, x, v, a);
-  prof_end(h, ln.stream);
+  a.rdx = h->fmt == FMT_F64 ? 1.0 / h->dx : (double)(1.0f / (float)h->dx);
+  a.c_prev = c_prev; a.c_cur = c_cur; a.d_cur = d_cur; a.c_next = h->cs[0];
+  a.scale = h->scale; a.n0 = h->cfg.n0;
+  a.to_units = 4294967296.0 / h->cfg.L;
+  SweepIO io;
+  io.acc_in = in_slot >= 0 ? ring_row(h, in_slot) : nullptr;
+  io.ext = ext;
+  io.acc_out = out;
+  io.acc_out2 = out2;
+  int z[2] = {-1, -1};
+  for (int k = 0; k < 2 && !h->dirty.empty(); ++k) {
+    z[k] = h->dirty.front();
+    h->dirty.erase(h->dirty.begin());
+  }
+  io.zero0 = z[0] >= 0 ? ring_row(h, z[0]) : nullptr;
+  io.zero1 = z[1] >= 0 ? ring_row(h, z[1]) : nullptr;
+  io.ke_part = h->ke_part;
+  io.bad = h->bad;
+  prof_begin(h, stage <= ST_D ? stage : 5);
+  if (h->fmt == FMT_F64) launch_sweep_p<PosF64>(h, io, stage, x, v, a);
+  else if (h->fmt == FMT_F32) launch_sweep_p<PosF32>(h, io, stage, x, v, a);
+  else launch_sweep_p<PosU32>(h, io, stage, x, v, a);
+  prof_end(h);
+  for (int k = 0; k < 2; ++k)
+    if (z[k] >= 0) h->clean.push_back(z[k]);      // zero for every LATER launch of this stream
 }
 
-struct SolveOut {
-  const double* slab = nullptr;   // default: h->part
-  const double* ext = nullptr;
-  const double* ke_part = nullptr;
-  double* n = nullptr; double* Ef = nullptr; double* E = nullptr; double* phi = nullptr;
-  double* KE = nullptr; double* PE = nullptr; double* PEr = nullptr;
-};
-
-SolveIO solve_io(pic_handle* h, const SolveOut& o) {
-  return SolveIO{o.slab ? o.slab : h->part, o.ext, o.ke_part, o.n, o.Ef, o.E, o.phi, o.KE, o.PE, o.PEr};
-}
-
-// one solve, or two independent ones in the same launch (second = nullptr for one)
-// rhs_rows > 0: the "slab" is a caller-supplied right-hand side of that many rows per environment, taken as it
-// is (scale 1, n0 0) instead of a deposit to be turned into n - n0 (pic_solve_poisson)
-void launch_solve(pic_handle* h, const Lane& ln, const SolveOut& o, const SolveOut* second = nullptr, int rhs_rows = 0) {
+void launch_solve(pic_handle* h, const SolveIO& io) {
   SolveArgs a;
-  a.env0 = ln.env0;
-  a.N = h->cfg.N; a.Ng = h->cfg.Ng; a.nblk = h->nblk; a.L = h->cfg.L; a.dx = h->dx; a.n0 = h->cfg.n0;
+  a.N = h->cfg.N; a.Ng = h->cfg.Ng; a.nblk = h->nblk; a.fg = h->fg; a.L = h->cfg.L; a.dx = h->dx; a.n0 = h->cfg.n0;
   a.scale = h->scale; a.N_over_L = (double)h->cfg.N / h->cfg.L;
-  if (rhs_rows > 0) { a.nblk = rhs_rows; a.scale = 1.0; a.n0 = 0.0; }
-  const SolveIO io0 = solve_io(h, o);
-  const SolveIO io1 = second ? solve_io(h, *second) : io0;
-  prof_begin(h, ln.stream, 4);
-  hipLaunchKernelGGL(field_solve_kernel, dim3(ln.nenv, second ? 2 : 1), dim3(SBLOCK), h->solve_lds, ln.stream, io0, io1, a);
-  prof_end(h, ln.stream);
+  prof_begin(h, 4);
+  hipLaunchKernelGGL(field_solve_kernel, dim3(h->cfg.num_envs), dim3(SBLOCK), h->solve_lds, h->stream, io, a);
+  prof_end(h);
+}
+
+// the post-step refresh (pic.py:145-146, no external field: pic.py:114-117) from the deposit in ring row `slot`
+void launch_final_solve(pic_handle* h, int slot) {
+  SolveIO o{};
+  o.acc = ring_row(h, slot);
+  o.ke_part = h->ke_part; o.n = h->n; o.E = h->E_mesh; o.phi = h->phi;
+  o.KE = h->KE; o.PE = h->PE; o.PEr = h->PEr;
+  launch_solve(h, o);
+  ring_retire(h, slot);
+}
+
+void drop_cached_deposits(pic_handle* h) {
+  ring_retire(h, h->q_slot);
+  ring_retire(h, h->stage_slot);
+  h->q_slot = h->stage_slot = -1;
+  h->mid_stage = 0;
 }
 
 int refresh_fields(pic_handle* h) {
-  Lane ln = whole(h);
-  launch_sweep(h, ln, ST_REFRESH, h->x, h->v, 0, 0, 0);
-  SolveOut o;
-  o.ke_part = h->ke_part; o.n = h->n; o.Ef = h->Ef; o.E = h->E_mesh; o.phi = h->phi;
-  o.KE = h->KE; o.PE = h->PE; o.PEr = h->PEr;
-  launch_solve(h, ln, o);
+  drop_cached_deposits(h);
+  const int f = ring_take_clean(h), qn = ring_take_clean(h);
+  launch_sweep(h, ST_REFRESH, h->x, h->v, 0, 0, 0, -1, nullptr, ring_row(h, f), ring_row(h, qn));
+  launch_final_solve(h, f);
   HIPCHK(h, hipGetLastError());
-  h->q1_ready = true;   // ST_REFRESH also deposited the next step's q1 into part2
+  h->q_slot = qn;   // ST_REFRESH also deposited the next step's q1
   return PIC_OK;
 }
 
-// copy a dense [env][N] caller array into a padded [env][ld] device array
+dim3 aux_grid(pic_handle* h, int nenv, long long cap = 1024) {
+  long long gx = (h->cfg.N + BLOCK - 1) / BLOCK;
+  if (gx > cap) gx = cap;
+  return dim3((unsigned)gx, nenv);
+}
+
+int ensure_stage(pic_handle* h) {
+  if (h->stage) return PIC_OK;
+  HIPCHK(h, hipMalloc(&h->stage, (size_t)h->cfg.num_envs * h->cfg.N * sizeof(float)));
+  return PIC_OK;
+}
+
+// copy a dense [env][N] caller array of velocities (or float positions) into a padded [env][ld] device array
 int upload(pic_handle* h, void* dst_padded, const void* src, int mem_kind) {
   const size_t row = (size_t)h->cfg.N * h->esz;
-  if (mem_kind == PIC_HOST) {
-    HIPCHK(h, hipMemcpy2DAsync(dst_padded, (size_t)h->ld * h->esz, src, row, row, h->cfg.num_envs,
-                               hipMemcpyHostToDevice, h->stream));
-  } else {
-    HIPCHK(h, hipMemcpy2DAsync(dst_padded, (size_t)h->ld * h->esz, src, row, row, h->cfg.num_envs,
-                               hipMemcpyDeviceToDevice, h->stream));
-  }
+  HIPCHK(h, hipMemcpy2DAsync(dst_padded, (size_t)h->ld * h->esz, src, row, row, h->cfg.num_envs,
+                             mem_kind == PIC_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, h->stream));
   return PIC_OK;
 }
 
-// mesh [env][Ng] gathered at the positions x [env][ld] with the handle's shape function -> out, dense [env][N]
-void launch_gather(pic_handle* h, const void* x, const double* mesh, void* out) {
-  long long gx = (h->cfg.N + BLOCK - 1) / BLOCK;
-  if (gx > 1024) gx = 1024;
-  dim3 grid((unsigned)gx, h->cfg.num_envs);
-  const size_t lds = ((size_t)h->cfg.Ng + 2) * h->esz;
-  const bool tsc = h->cfg.interpol == PIC_TSC;
-  if (h->cfg.particle_dtype == PIC_F64) {
-    if (tsc) hipLaunchKernelGGL((gather_E_kernel<double, PIC_TSC>), grid, dim3(BLOCK), lds, h->stream, (const double*)x, mesh, (double*)out, h->cfg.N, h->ld, h->cfg.Ng, h->cfg.L, h->dx);
-    else hipLaunchKernelGGL((gather_E_kernel<double, PIC_CIC>), grid, dim3(BLOCK), lds, h->stream, (const double*)x, mesh, (double*)out, h->cfg.N, h->ld, h->cfg.Ng, h->cfg.L, h->dx);
-  } else {
-    if (tsc) hipLaunchKernelGGL((gather_E_kernel<float, PIC_TSC>), grid, dim3(BLOCK), lds, h->stream, (const float*)x, mesh, (float*)out, h->cfg.N, h->ld, h->cfg.Ng, h->cfg.L, h->dx);
-    else hipLaunchKernelGGL((gather_E_kernel<float, PIC_CIC>), grid, dim3(BLOCK), lds, h->stream, (const float*)x, mesh, (float*)out, h->cfg.N, h->ld, h->cfg.Ng, h->cfg.L, h->dx);
+// positions arrive as floats of the particle dtype; the fixed-point format converts them on the device
+int upload_positions(pic_handle* h, void* dst_padded, const void* src, int mem_kind) {
+  if (h->fmt != FMT_U32) return upload(h, dst_padded, src, mem_kind);
+  const float* dsrc = static_cast<const float*>(src);
+  if (mem_kind == PIC_HOST) {
+    int rc = ensure_stage(h);
+    if (rc) return rc;
+    HIPCHK(h, hipMemcpyAsync(h->stage, src, (size_t)h->cfg.num_envs * h->cfg.N * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    dsrc = static_cast<const float*>(h->stage);
   }
-}
-
-// indices and weights of `nenv` environments' worth of positions x [nenv][ld] -> idx, w [nenv][3][N]
-void launch_shape_query(pic_handle* h, const void* x, int nenv, int shape, long long* idx, double* w) {
-  long long gx = (h->cfg.N + BLOCK - 1) / BLOCK;
-  if (gx > 1024) gx = 1024;
-  dim3 grid((unsigned)gx, nenv);
-  const bool tsc = shape == PIC_TSC;
-  if (h->cfg.particle_dtype == PIC_F64) {
-    if (tsc) hipLaunchKernelGGL((shape_query_kernel<double, PIC_TSC>), grid, dim3(BLOCK), 0, h->stream, (const double*)x, h->cfg.N, h->ld, h->cfg.Ng, h->cfg.L, h->dx, idx, w);
-    else hipLaunchKernelGGL((shape_query_kernel<double, PIC_CIC>), grid, dim3(BLOCK), 0, h->stream, (const double*)x, h->cfg.N, h->ld, h->cfg.Ng, h->cfg.L, h->dx, idx, w);
-  } else {
-    if (tsc) hipLaunchKernelGGL((shape_query_kernel<float, PIC_TSC>), grid, dim3(BLOCK), 0, h->stream, (const float*)x, h->cfg.N, h->ld, h->cfg.Ng, h->cfg.L, h->dx, idx, w);
-    else hipLaunchKernelGGL((shape_query_kernel<float, PIC_CIC>), grid, dim3(BLOCK), 0, h->stream, (const float*)x, h->cfg.N, h->ld, h->cfg.Ng, h->cfg.L, h->dx, idx, w);
-  }
+  hipLaunchKernelGGL((positions_in_kernel<PosU32, float>), aux_grid(h, h->cfg.num_envs), dim3(BLOCK), 0, h->stream, dsrc,
+                     static_cast<unsigned*>(dst_padded), h->cfg.N, h->ld, h->cfg.L, h->bad);
+  HIPCHK(h, hipGetLastError());
+  return PIC_OK;
 }
 
 int download(pic_handle* h, void* dst, const void* src_padded, int mem_kind) {
@@ -350,6 +350,57 @@ int download(pic_handle* h, void* dst, const void* src_padded, int mem_kind) {
   HIPCHK(h, hipMemcpy2DAsync(dst, row, src_padded, (size_t)h->ld * h->esz, row, h->cfg.num_envs,
                              mem_kind == PIC_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, h->stream));
   return PIC_OK;
+}
+
+int download_positions(pic_handle* h, void* dst, const void* src_padded, int mem_kind) {
+  if (h->fmt != FMT_U32) return download(h, dst, src_padded, mem_kind);
+  float* ddst = static_cast<float*>(dst);
+  if (mem_kind == PIC_HOST) {
+    int rc = ensure_stage(h);
+    if (rc) return rc;
+    ddst = static_cast<float*>(h->stage);
+  }
+  hipLaunchKernelGGL((positions_out_kernel<PosU32, float>), aux_grid(h, h->cfg.num_envs), dim3(BLOCK), 0, h->stream,
+                     static_cast<const unsigned*>(src_padded), ddst, h->cfg.N, h->ld, h->cfg.L);
+  HIPCHK(h, hipGetLastError());
+  if (mem_kind == PIC_HOST)
+    HIPCHK(h, hipMemcpyAsync(dst, h->stage, (size_t)h->cfg.num_envs * h->cfg.N * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+  return PIC_OK;
+}
+
+// mesh [env][Ng] gathered at the positions x [env][ld] with the handle's shape function -> out, dense [env][N]
+template <typename P>
+void launch_gather_p(pic_handle* h, const void* x, const double* mesh, void* out) {
+  const dim3 grid = aux_grid(h, h->cfg.num_envs);
+  const size_t lds = ((size_t)h->cfg.Ng + 2) * sizeof(typename P::W);
+  if (h->cfg.interpol == PIC_TSC)
+    hipLaunchKernelGGL((gather_E_kernel<P, PIC_TSC>), grid, dim3(BLOCK), lds, h->stream, (const typename P::X*)x, mesh,
+                       (typename P::W*)out, h->cfg.N, h->ld, h->cfg.Ng, h->cfg.L, h->dx);
+  else
+    hipLaunchKernelGGL((gather_E_kernel<P, PIC_CIC>), grid, dim3(BLOCK), lds, h->stream, (const typename P::X*)x, mesh,
+                       (typename P::W*)out, h->cfg.N, h->ld, h->cfg.Ng, h->cfg.L, h->dx);
+}
+void launch_gather(pic_handle* h, const void* x, const double* mesh, void* out) {
+  if (h->fmt == FMT_F64) launch_gather_p<PosF64>(h, x, mesh, out);
+  else if (h->fmt == FMT_F32) launch_gather_p<PosF32>(h, x, mesh, out);
+  else launch_gather_p<PosU32>(h, x, mesh, out);
+}
+
+// indices and weights of `nenv` environments' worth of positions x [nenv][ld] -> idx, w [nenv][3][N]
+template <typename P>
+void launch_shape_query_p(pic_handle* h, const void* x, int nenv, int shape, long long* idx, double* w) {
+  const dim3 grid = aux_grid(h, nenv);
+  if (shape == PIC_TSC)
+    hipLaunchKernelGGL((shape_query_kernel<P, PIC_TSC>), grid, dim3(BLOCK), 0, h->stream, (const typename P::X*)x, h->cfg.N,
+                       h->ld, h->cfg.Ng, h->cfg.L, h->dx, idx, w);
+  else
+    hipLaunchKernelGGL((shape_query_kernel<P, PIC_CIC>), grid, dim3(BLOCK), 0, h->stream, (const typename P::X*)x, h->cfg.N,
+                       h->ld, h->cfg.Ng, h->cfg.L, h->dx, idx, w);
+}
+void launch_shape_query(pic_handle* h, const void* x, int nenv, int shape, long long* idx, double* w) {
+  if (h->fmt == FMT_F64) launch_shape_query_p<PosF64>(h, x, nenv, shape, idx, w);
+  else if (h->fmt == FMT_F32) launch_shape_query_p<PosF32>(h, x, nenv, shape, idx, w);
+  else launch_shape_query_p<PosU32>(h, x, nenv, shape, idx, w);
 }
 
 }  // namespace
@@ -365,18 +416,25 @@ int pic_create(const pic_config* cfg, pic_handle** out) {
   *out = nullptr;
   if (cfg->N < 1 || cfg->Ng < 4 || cfg->num_envs < 1 || !(cfg->L > 0) || !(cfg->dt > 0) || !(cfg->n0 > 0))
     return fail(nullptr, PIC_EINVAL, "pic_create: need N>=1, Ng>=4, num_envs>=1, L>0, dt>0, n0>0");
+  if (cfg->N > (1ll << 36)) return fail(nullptr, PIC_EINVAL, "pic_create: N > 2^36");
   if (cfg->num_envs > 65535) return fail(nullptr, PIC_EINVAL, "pic_create: num_envs > 65535");
   if (cfg->env_index_base < 0) return fail(nullptr, PIC_EINVAL, "pic_create: env_index_base < 0");
   if (cfg->particle_dtype != PIC_F64 && cfg->particle_dtype != PIC_F32)
     return fail(nullptr, PIC_EINVAL, "pic_create: particle_dtype must be PIC_F64 or PIC_F32");
-  if (cfg->accum_dtype != PIC_F64 && cfg->accum_dtype != PIC_F32 && cfg->accum_dtype != PIC_FIXED)
-    return fail(nullptr, PIC_EINVAL, "pic_create: accum_dtype must be PIC_F64, PIC_F32 or PIC_FIXED");
-  if (cfg->accum_dtype != PIC_F64 && cfg->particle_dtype != PIC_F32)
-    return fail(nullptr, PIC_EINVAL, "pic_create: a float32 or fixed-point accumulator needs float32 particles");
+  if (cfg->position_dtype != PIC_POS_FLOAT && cfg->position_dtype != PIC_POS_FIXED32)
+    return fail(nullptr, PIC_EINVAL, "pic_create: position_dtype must be PIC_POS_FLOAT or PIC_POS_FIXED32");
+  if (cfg->position_dtype == PIC_POS_FIXED32 && cfg->particle_dtype != PIC_F32)
+    return fail(nullptr, PIC_EINVAL, "pic_create: 32-bit fixed-point positions go with float32 particles");
+  if (cfg->accum_dtype < PIC_ACC_AUTO || cfg->accum_dtype > PIC_ACC_F64)
+    return fail(nullptr, PIC_EINVAL, "pic_create: accum_dtype must be PIC_ACC_AUTO, _FIX64, _PACKED or _F64");
   if (cfg->interpol != PIC_CIC && cfg->interpol != PIC_TSC)
     return fail(nullptr, PIC_EINVAL, "pic_create: interpol must be PIC_CIC or PIC_TSC");
-  if (cfg->accum_dtype == PIC_FIXED && cfg->interpol != PIC_CIC)
-    return fail(nullptr, PIC_EINVAL, "pic_create: the fixed-point accumulator is CIC only");
+  if (cfg->accum_dtype == PIC_ACC_PACKED && cfg->particle_dtype != PIC_F32)
+    return fail(nullptr, PIC_EINVAL, "pic_create: the packed accumulator needs float32 particles");
+  if (cfg->accum_dtype == PIC_ACC_PACKED && cfg->interpol != PIC_CIC)
+    return fail(nullptr, PIC_EINVAL, "pic_create: the packed accumulator is CIC only");
+  if (cfg->accum_dtype == PIC_ACC_F64 && cfg->particle_dtype != PIC_F64)
+    return fail(nullptr, PIC_EINVAL, "pic_create: the float64 accumulator needs float64 particles");
 
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
@@ -386,13 +444,21 @@ int pic_create(const pic_config* cfg, pic_handle** out) {
   pic_handle* h = new (std::nothrow) pic_handle();
   if (!h) return fail(nullptr, PIC_ENOMEM, "pic_create: out of host memory");
   h->cfg = *cfg;
+  h->fmt = cfg->particle_dtype == PIC_F64 ? FMT_F64 : (cfg->position_dtype == PIC_POS_FIXED32 ? FMT_U32 : FMT_F32);
+  h->acc_kind = cfg->accum_dtype;
+  if (h->acc_kind == PIC_ACC_AUTO)
+    h->acc_kind = (cfg->particle_dtype == PIC_F32 && cfg->interpol == PIC_CIC) ? PIC_ACC_PACKED : PIC_ACC_FIX64;
   h->esz = cfg->particle_dtype == PIC_F64 ? 8 : 4;
-  h->asz = cfg->accum_dtype == PIC_F32 ? 4 : 8;
   h->vec = cfg->particle_dtype == PIC_F64 ? 2 : 4;
   h->dx = cfg->L / cfg->Ng;                                   // pic.py:36
   h->scale = cfg->n0 * cfg->L / (double)cfg->N / h->dx;       // interpolate.py:18
   yoshida_coefficients(h->cs, h->ds);
   h->ld = (cfg->N + 63) / 64 * 64;
+  // fixed-point accumulators: the weights of all N particles on one node must fit in 63 bits
+  int lg = 0;
+  while ((1ll << lg) < cfg->N + 1) ++lg;
+  h->fg = 62 - lg > 50 ? 50 : 62 - lg;
+  h->magic = std::ldexp(1.5, 52 - h->fg);
 
   // workgroups per environment: enough in total to fill 256 CUs several times, at least one
   // BLOCK*VEC tile each
@@ -401,9 +467,9 @@ int pic_create(const pic_config* cfg, pic_handle** out) {
   if (nblk <= 0) {
     const long long target_total = 8192;      // ~128 workgroups per env at 64 envs (profiles/experiments_r1.md)
     nblk = (target_total + cfg->num_envs - 1) / cfg->num_envs;
-    // Large problems: >= 8 tiles per workgroup (amortises the prologue and the slab row).  Small, launch-bound
+    // Large problems: >= 8 tiles per workgroup (amortises the prologue and the flush).  Small, launch-bound
     // problems (profiles/smalln_bpe.py: N = 1e4 41 -> 30 us/step, N = 5e3 36 -> 28 us/step): one tile per
-    // workgroup, at most 64 workgroups per environment so that the fused prologue solve stays cheap.
+    // workgroup, at most 64 workgroups per environment.
     const bool small = (double)cfg->N * cfg->num_envs <= 4.0e6;
     const long long tiles_min = small ? 1 : 8;
     long long max_by_work = (cfg->N + tiles_min * tile - 1) / (tiles_min * tile);
@@ -411,7 +477,7 @@ int pic_create(const pic_config* cfg, pic_handle** out) {
     if (nblk > max_by_work) nblk = max_by_work;
     if (nblk < 1) nblk = 1;
   }
-  if (cfg->accum_dtype == PIC_FIXED) {       // count field of the packed accumulator: < 2^20 particles per workgroup
+  if (h->acc_kind == PIC_ACC_PACKED) {       // count field of the packed accumulator: < 2^20 particles per workgroup
     const long long cap = (1ll << 20) - tile;
     if (nblk < (cfg->N + cap - 1) / cap) nblk = (cfg->N + cap - 1) / cap;
   }
@@ -419,10 +485,6 @@ int pic_create(const pic_config* cfg, pic_handle** out) {
   chunk = (chunk + tile - 1) / tile * tile;
   nblk = (cfg->N + chunk - 1) / chunk;
   if (nblk > 65535) { delete h; return fail(nullptr, PIC_EINVAL, "pic_create: blocks_per_env too large"); }
-  if (const char* rt = getenv("PICSTEP_RUN_TILES")) {      // experiment knob: interleave runs of this many tiles
-    const long long k = atoll(rt);
-    if (k > 0) chunk = k * tile;
-  }
   h->chunk = chunk;
   h->nblk = (int)nblk;
 
@@ -430,11 +492,10 @@ int pic_create(const pic_config* cfg, pic_handle** out) {
   // LDS: 2 R meshes (sweep D deposits two) + the field tile; up to 4 mesh copies (waves w and w+4 share
   // one: 8 copies measured no better) while the workgroup stays within 40 KB, i.e. 4 workgroups per CU
   h->R = WAVES < 4 ? WAVES : 4;
-  if (const char* mr = getenv("PICSTEP_MAX_R")) { const int m = atoi(mr); while (m >= 1 && h->R > m) h->R >>= 1; }
-  while (h->R > 1 && 2 * h->R * stride * h->asz + stride * h->esz > 40 * 1024) h->R >>= 1;
-  h->sweep_lds = 2 * h->R * stride * h->asz + stride * h->esz;
-  h->solve_lds = (2 + SGROUPS) * (size_t)cfg->Ng * sizeof(double);
-  if (h->sweep_lds > 64 * 1024 || h->solve_lds > 150 * 1024) {
+  while (h->R > 1 && 2 * h->R * stride * 8 + stride * h->esz > 40 * 1024) h->R >>= 1;
+  h->sweep_lds = 2 * h->R * stride * 8 + stride * h->esz;
+  h->solve_lds = 2 * (size_t)cfg->Ng * sizeof(double);
+  if (h->sweep_lds > 64 * 1024) {
     delete h;
     return fail(nullptr, PIC_EINVAL, "pic_create: Ng too large for the LDS-resident mesh (max 2700 cells)");
   }
@@ -450,63 +511,21 @@ int pic_create(const pic_config* cfg, pic_handle** out) {
   } while (0)
 
   CREATE_CHK(hipSetDevice(cfg->device_id));
-  if (h->solve_lds > 64 * 1024)
-    CREATE_CHK(hipFuncSetAttribute((const void*)field_solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)h->solve_lds));
   CREATE_CHK(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
   h->stream = h->own_stream;
-  {
-    // hipGraph replay of a step (PICSTEP_GRAPH=1).  Off by default: at N = 1e4 the 7 dependent kernels cost
-    // ~7 us each on the device whichever way they are launched (50.4 us/step eager, 53.9 us/step replayed).
-    const char* ug = getenv("PICSTEP_GRAPH");
-    h->use_graph = ug && atoi(ug) != 0;
-  }
-  {
-    // group size: particles (x and v) of a group <= PICSTEP_GROUP_MB; 0 disables grouping
-    const char* gm = getenv("PICSTEP_GROUP_MB");
-    const char* ns = getenv("PICSTEP_STREAMS");
-    const char* sm = getenv("PICSTEP_STEP_MAJOR");
-    const double group_mb = gm ? atof(gm) : 0.0;
-    const int nstreams = ns ? atoi(ns) : 2;
-    h->group_major = !(sm && atoi(sm) != 0);
-    const double env_mb = 2.0 * (double)h->ld * (double)h->esz / (1024.0 * 1024.0);
-    if (group_mb > 0 && nstreams >= 1) {
-      int G = (int)(group_mb / env_mb);
-      if (G < 1) G = 1;
-      if (G < cfg->num_envs) {
-        h->group_envs = G;
-        CREATE_CHK(hipEventCreateWithFlags(&h->fork_ev, hipEventDisableTiming));
-        for (int w = 0; w < nstreams; ++w) {
-          hipStream_t st;
-          hipEvent_t ev;
-          CREATE_CHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-          h->wstreams.push_back(st);
-          CREATE_CHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-          h->join_ev.push_back(ev);
-        }
-      }
-    }
-  }
   const size_t pbytes = (size_t)cfg->num_envs * h->ld * h->esz;
   const size_t gbytes = (size_t)cfg->num_envs * cfg->Ng * sizeof(double);
   CREATE_CHK(hipMalloc(&h->x, pbytes));
   CREATE_CHK(hipMalloc(&h->v, pbytes));
   CREATE_CHK(hipMemsetAsync(h->x, 0, pbytes, h->stream));
   CREATE_CHK(hipMemsetAsync(h->v, 0, pbytes, h->stream));
-  CREATE_CHK(hipMalloc((void**)&h->part, gbytes * h->nblk));
-  CREATE_CHK(hipMalloc((void**)&h->part2, gbytes * h->nblk));
-  CREATE_CHK(hipMalloc((void**)&h->part_b, gbytes * h->nblk));
-  {
-    // Every sweep workgroup re-sums its environment's nblk slab rows, so this pays where a step is
-    // launch-bound (config 1: 50.0 -> 40.7 us/step) and is neutral once the sweeps are HBM-bound (config 2:
-    // 1.229 vs 1.224 ms/step): on by default for small problems only.  PICSTEP_FUSED_SOLVE=0/1 overrides.
-    if (const char* ps = getenv("PICSTEP_PAIR_SOLVES")) h->pair_solves = atoi(ps) != 0;
-    const char* fs = getenv("PICSTEP_FUSED_SOLVE");
-    h->fused_solve = fs ? atoi(fs) != 0 : (h->nblk <= 64 && (double)cfg->N * cfg->num_envs <= 4.0e6);
-  }
+  CREATE_CHK(hipMalloc((void**)&h->ring, (size_t)(RING + 1) * gbytes));      // acc_t and double are both 8 bytes
+  CREATE_CHK(hipMemsetAsync(h->ring, 0, (size_t)(RING + 1) * gbytes, h->stream));
+  h->probe_acc = h->ring + (size_t)RING * cfg->num_envs * cfg->Ng;
+  for (int s = 0; s < RING; ++s) h->clean.push_back(s);
   CREATE_CHK(hipMalloc((void**)&h->ke_part, (size_t)cfg->num_envs * h->nblk * sizeof(double)));
   CREATE_CHK(hipMemsetAsync(h->ke_part, 0, (size_t)cfg->num_envs * h->nblk * sizeof(double), h->stream));
-  double** grids[] = {&h->Ef, &h->n, &h->E_mesh, &h->phi, &h->ext, &h->aux_n, &h->aux_E};
+  double** grids[] = {&h->n, &h->E_mesh, &h->phi, &h->ext, &h->probe_ext, &h->aux_n, &h->aux_E, &h->aux_phi};
   for (double** g : grids) {
     CREATE_CHK(hipMalloc((void**)g, gbytes));
     CREATE_CHK(hipMemsetAsync(*g, 0, gbytes, h->stream));
@@ -521,8 +540,8 @@ int pic_create(const pic_config* cfg, pic_handle** out) {
   CREATE_CHK(hipHostMalloc((void**)&h->h_scal, 3 * sbytes, hipHostMallocDefault));
   CREATE_CHK(hipMalloc((void**)&h->aux_pe, sbytes));
   CREATE_CHK(hipMemsetAsync(h->aux_pe, 0, sbytes, h->stream));
-  CREATE_CHK(hipMalloc((void**)&h->bad, 4 * sizeof(unsigned long long)));   // [0] bad positions, [1..3] diagnostics
-  CREATE_CHK(hipMemsetAsync(h->bad, 0, 4 * sizeof(unsigned long long), h->stream));
+  CREATE_CHK(hipMalloc((void**)&h->bad, sizeof(unsigned long long)));
+  CREATE_CHK(hipMemsetAsync(h->bad, 0, sizeof(unsigned long long), h->stream));
   CREATE_CHK(hipStreamSynchronize(h->stream));
 #undef CREATE_CHK
   *out = h;
@@ -535,19 +554,11 @@ int pic_destroy(pic_handle* h) {
   if (h->stream) hipStreamSynchronize(h->stream);
   prof_drain(h);
   for (hipEvent_t e : h->ev) hipEventDestroy(e);
-  if (h->basis) hipFree(h->basis);
-  if (h->act) hipFree(h->act);
-  if (h->modes) hipFree(h->modes);
-  void* bufs[] = {h->x, h->v, h->scratch, h->part, h->part2, h->part_b, h->ke_part, h->Ef, h->n, h->E_mesh, h->phi, h->ext,
-                  h->aux_n, h->aux_E, h->aux_pe, h->aux_phi, h->KE, h->bad};
+  void* bufs[] = {h->x, h->v, h->scratch, h->stage, h->ring, h->ke_part, h->n, h->E_mesh, h->phi, h->ext, h->probe_ext,
+                  h->basis, h->act, h->modes, h->aux_n, h->aux_E, h->aux_pe, h->aux_phi, h->KE, h->bad};
   for (void* b : bufs)
     if (b) hipFree(b);
   if (h->h_scal) hipHostFree(h->h_scal);
-  for (StepGraph& g : h->graphs)
-    if (g.exec) hipGraphExecDestroy(g.exec);
-  for (hipStream_t st : h->wstreams) hipStreamDestroy(st);
-  for (hipEvent_t ev : h->join_ev) hipEventDestroy(ev);
-  if (h->fork_ev) hipEventDestroy(h->fork_ev);
   if (h->own_stream) hipStreamDestroy(h->own_stream);
   delete h;
   return PIC_OK;
@@ -558,9 +569,6 @@ int pic_set_stream(pic_handle* h, void* hip_stream) {
   HIPCHK(h, hipSetDevice(h->cfg.device_id));
   HIPCHK(h, hipStreamSynchronize(h->stream));      // drain the old stream: later work must see its results
   prof_drain(h);
-  for (StepGraph& g : h->graphs)                    // captured on the old stream's behalf; cheap to rebuild
-    if (g.exec) hipGraphExecDestroy(g.exec);
-  h->graphs.clear();
   h->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : h->own_stream;
   return PIC_OK;
 }
@@ -575,14 +583,19 @@ int pic_sync(pic_handle* h) {
 int pic_set_particles(pic_handle* h, const void* x, const void* v, int mem_kind) {
   if (!h || !x || !v) return fail(h, PIC_EINVAL, "pic_set_particles: null argument");
   HIPCHK(h, hipSetDevice(h->cfg.device_id));
-  int rc = upload(h, h->x, x, mem_kind);
+  int rc = upload_positions(h, h->x, x, mem_kind);
   if (rc) return rc;
   rc = upload(h, h->v, v, mem_kind);
   if (rc) return rc;
   if (mem_kind == PIC_HOST) HIPCHK(h, hipStreamSynchronize(h->stream));
   h->has_state = true;
-  h->q1_ready = false;
-  h->mid_stage = 0;
+  drop_cached_deposits(h);
+  return PIC_OK;
+}
+
+int pic_invalidate(pic_handle* h) {
+  if (!h) return PIC_EINVAL;
+  drop_cached_deposits(h);
   return PIC_OK;
 }
 
@@ -594,10 +607,56 @@ int pic_refresh(pic_handle* h) {
 }
 
 int pic_reset(pic_handle* h, const void* x0, const void* v0, int mem_kind) {
+  if (!h) return PIC_EINVAL;
+  HIPCHK(h, hipSetDevice(h->cfg.device_id));
+  HIPCHK(h, hipMemsetAsync(h->bad, 0, sizeof(unsigned long long), h->stream));
   int rc = pic_set_particles(h, x0, v0, mem_kind);
   if (rc) return rc;
-  HIPCHK(h, hipMemsetAsync(h->bad, 0, sizeof(unsigned long long), h->stream));
   return refresh_fields(h);
+}
+
+// the sweeps of one environment step; `upto`: 1 = through sweep B, 2 = through C, 3 = whole step.  from: first
+// stage to run (1, 2, 3).  Each force evaluation takes `ext` (may differ per stage in the staged entry point).
+static void run_stages(pic_handle* h, int from, int upto, const double* ext) {
+  const double* c = h->cs;
+  const double* d = h->ds;
+  for (int st = from; st <= upto; ++st) {
+    if (st == 1) {
+      if (h->q_slot < 0) {          // particles were loaded without a refresh: deposit q1 = x + (c1 v) dt now
+        h->q_slot = ring_take_clean(h);
+        launch_sweep(h, ST_A, h->x, h->v, 0.0, c[0], 0.0, -1, nullptr, ring_row(h, h->q_slot), nullptr);
+      }
+      const int x1 = ring_take_clean(h);
+      launch_sweep(h, ST_B, h->x, h->v, c[0], c[1], d[1], h->q_slot, ext, ring_row(h, x1), nullptr);
+      ring_retire(h, h->q_slot);
+      h->q_slot = -1;
+      h->stage_slot = x1;
+    } else if (st == 2) {
+      const int x2 = ring_take_clean(h);
+      launch_sweep(h, ST_C, h->x, h->v, 0.0, c[2], d[2], h->stage_slot, ext, ring_row(h, x2), nullptr);
+      ring_retire(h, h->stage_slot);
+      h->stage_slot = x2;
+    } else {
+      const int f = ring_take_clean(h), qn = ring_take_clean(h);
+      launch_sweep(h, ST_D, h->x, h->v, 0.0, c[3], d[3], h->stage_slot, ext, ring_row(h, f), ring_row(h, qn));
+      ring_retire(h, h->stage_slot);
+      h->stage_slot = -1;
+      launch_final_solve(h, f);
+      h->q_slot = qn;
+    }
+  }
+}
+
+static int stage_ext(pic_handle* h, const double* E_ext, int mem_kind, const double** ext) {
+  *ext = nullptr;
+  if (!E_ext) return PIC_OK;
+  *ext = E_ext;
+  if (mem_kind == PIC_HOST) {
+    HIPCHK(h, hipMemcpyAsync(h->ext, E_ext, (size_t)h->cfg.num_envs * h->cfg.Ng * sizeof(double), hipMemcpyHostToDevice,
+                             h->stream));
+    *ext = h->ext;
+  }
+  return PIC_OK;
 }
 
 int pic_step_stage(pic_handle* h, int stage, const double* E_ext, int mem_kind) {
@@ -606,42 +665,10 @@ int pic_step_stage(pic_handle* h, int stage, const double* E_ext, int mem_kind) 
   if (stage < 1 || stage > 3 || stage != h->mid_stage + 1)
     return fail(h, PIC_ESTATE, "pic_step_stage: stages run in the order 1, 2, 3");
   HIPCHK(h, hipSetDevice(h->cfg.device_id));
-  const double* ext = nullptr;
-  if (E_ext) {
-    ext = E_ext;
-    if (mem_kind == PIC_HOST) {
-      HIPCHK(h, hipMemcpyAsync(h->ext, E_ext, (size_t)h->cfg.num_envs * h->cfg.Ng * sizeof(double),
-                               hipMemcpyHostToDevice, h->stream));
-      ext = h->ext;
-    }
-  }
-  const double* c = h->cs;
-  const double* d = h->ds;
-  Lane ln = whole(h);
-  ln.parity = h->sweep_parity;
-  SolveOut f;                      // force evaluation with THIS stage's external field
-  f.ext = ext; f.Ef = h->Ef;
-  if (stage == 1) {
-    if (h->q1_ready) {
-      f.slab = h->part2;           // q1 was deposited by the previous sweep D / reset
-    } else {
-      launch_sweep(h, ln, ST_A, h->x, h->v, 0.0, c[0], 0.0);
-    }
-    launch_solve(h, ln, f);
-    launch_sweep(h, ln, ST_B, h->x, h->v, c[0], c[1], d[1]);
-  } else if (stage == 2) {
-    launch_solve(h, ln, f);
-    launch_sweep(h, ln, ST_C, h->x, h->v, 0.0, c[2], d[2]);
-  } else {
-    launch_solve(h, ln, f);
-    launch_sweep(h, ln, ST_D, h->x, h->v, 0.0, c[3], d[3]);
-    SolveOut o;                    // post-step refresh: no external field (pic.py:114-117)
-    o.ke_part = h->ke_part; o.n = h->n; o.E = h->E_mesh; o.phi = h->phi;
-    o.KE = h->KE; o.PE = h->PE; o.PEr = h->PEr;
-    launch_solve(h, ln, o);
-    h->q1_ready = true;
-  }
-  h->sweep_parity = ln.parity;
+  const double* ext;
+  int rc = stage_ext(h, E_ext, mem_kind, &ext);
+  if (rc) return rc;
+  run_stages(h, stage, stage, ext);
   h->mid_stage = stage == 3 ? 0 : stage;
   HIPCHK(h, hipGetLastError());
   return PIC_OK;
@@ -653,144 +680,10 @@ int pic_step(pic_handle* h, const double* E_ext, int mem_kind, int nsteps) {
   if (nsteps < 0) return fail(h, PIC_EINVAL, "pic_step: nsteps < 0");
   if (h->mid_stage) return fail(h, PIC_ESTATE, "pic_step: a staged step is in progress (finish pic_step_stage 1..3)");
   HIPCHK(h, hipSetDevice(h->cfg.device_id));
-  const double* ext = nullptr;
-  if (E_ext) {
-    if (mem_kind == PIC_HOST) {
-      HIPCHK(h, hipMemcpyAsync(h->ext, E_ext, (size_t)h->cfg.num_envs * h->cfg.Ng * sizeof(double),
-                               hipMemcpyHostToDevice, h->stream));
-      ext = h->ext;
-    } else {
-      ext = E_ext;
-    }
-  }
-  // One environment step on a lane (7 launches): solve(q1 slab) B solve C solve D solve(final).
-  const double* c = h->cs;
-  const double* d = h->ds;
-  const bool q1_ready = h->q1_ready;
-  auto one_step = [&](Lane& ln, bool have_q1, bool ef_ready = false, bool pair_next = false) {
-    if (h->fused_solve) {
-      // 4 launches: the three force-evaluation solves run in the prologue of the sweep that needs the field.
-      // Slabs are double-buffered: a workgroup that starts late must still find the rows of the PREVIOUS sweep.
-      SweepIO io;
-      if (!have_q1) {
-        io.out = h->part2;                       // sweep A deposits q1 where sweep D normally leaves it
-        launch_sweep(h, ln, ST_A, h->x, h->v, 0.0, c[0], 0.0, io);
-      }
-      io = SweepIO(); io.slab_in = h->part2; io.ext = ext; io.out = h->part;
-      launch_sweep(h, ln, ST_B, h->x, h->v, c[0], c[1], d[1], io);
-      io = SweepIO(); io.slab_in = h->part; io.ext = ext; io.out = h->part_b;
-      launch_sweep(h, ln, ST_C, h->x, h->v, 0.0, c[2], d[2], io);
-      io = SweepIO(); io.slab_in = h->part_b; io.ext = ext; io.out = h->part; io.out2 = h->part2;
-      launch_sweep(h, ln, ST_D, h->x, h->v, 0.0, c[3], d[3], io);
-      SolveOut o;           // post-step refresh: no external field (pic.py:114-117)
-      o.ke_part = h->ke_part; o.n = h->n; o.E = h->E_mesh; o.phi = h->phi;
-      o.KE = h->KE; o.PE = h->PE; o.PEr = h->PEr;
-      launch_solve(h, ln, o);
-      return;
-    }
-    SolveOut f;           // force evaluation: only the gather field is needed
-    f.ext = ext; f.Ef = h->Ef;
-    if (ef_ready) {
-      // the previous step's last launch already solved for this step's first force evaluation
-    } else if (have_q1) {   // the previous sweep D / reset already deposited q1 = x + (c1 v) dt
-      SolveOut f1 = f;
-      f1.slab = h->part2;
-      launch_solve(h, ln, f1);
-    } else {
-      launch_sweep(h, ln, ST_A, h->x, h->v, 0.0, c[0], 0.0);
-      launch_solve(h, ln, f);
-    }
-    launch_sweep(h, ln, ST_B, h->x, h->v, c[0], c[1], d[1]);
-    launch_solve(h, ln, f);
-    launch_sweep(h, ln, ST_C, h->x, h->v, 0.0, c[2], d[2]);
-    launch_solve(h, ln, f);
-    launch_sweep(h, ln, ST_D, h->x, h->v, 0.0, c[3], d[3]);
-    SolveOut o;           // post-step refresh: no external field (pic.py:114-117)
-    o.ke_part = h->ke_part; o.n = h->n; o.E = h->E_mesh; o.phi = h->phi;
-    o.KE = h->KE; o.PE = h->PE; o.PEr = h->PEr;
-    if (pair_next) {      // another step follows with the same E_ext: solve its first force field in this launch too
-      SolveOut f1 = f;
-      f1.slab = h->part2;
-      launch_solve(h, ln, o, &f1);
-    } else {
-      launch_solve(h, ln, o);
-    }
-  };
-
-  const int E = h->cfg.num_envs;
-  const int G = h->group_envs;
-  if (G <= 0 || G >= E || h->wstreams.empty() || nsteps == 0) {
-    Lane ln = whole(h);
-    ln.parity = h->sweep_parity;
-    for (int s = 0; s < nsteps; ++s) {
-      const bool have_q1 = s > 0 || q1_ready;
-      if (!h->use_graph || !have_q1) {
-        // unfused schedule: 7 launches for a lone step, 6 per step inside a multi-step call
-        const bool pairing = !h->fused_solve && h->pair_solves;
-        one_step(ln, have_q1, /*ef_ready=*/pairing && s > 0, /*pair_next=*/pairing && s + 1 < nsteps);
-        continue;
-      }
-      if (h->prof) {
-        one_step(ln, have_q1);
-        continue;
-      }
-      // Launch-bound regime (small environments): the 7 launches of a step are replayed from a hipGraph.
-      // A graph bakes in the kernel arguments, i.e. the external-field pointer and the direction parity
-      // the step starts with (it flips every step), so executables are cached per (ext, parity).
-      StepGraph* g = nullptr;
-      for (StepGraph& c : h->graphs)
-        if (c.exec && c.ext == ext && c.parity == ln.parity) { g = &c; break; }
-      if (!g) {
-        if (h->graphs.size() >= 8) {               // bounded cache: drop the oldest executable
-          hipGraphExecDestroy(h->graphs.front().exec);
-          h->graphs.erase(h->graphs.begin());
-        }
-        hipGraph_t graph = nullptr;
-        Lane cap = ln;
-        HIPCHK(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
-        one_step(cap, true);
-        HIPCHK(h, hipStreamEndCapture(h->stream, &graph));
-        StepGraph ng;
-        ng.ext = ext; ng.parity = ln.parity; ng.parity_out = cap.parity;
-        hipError_t ge = hipGraphInstantiate(&ng.exec, graph, nullptr, nullptr, 0);
-        hipGraphDestroy(graph);
-        if (ge != hipSuccess) return fail(h, PIC_EHIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(ge));
-        h->graphs.push_back(ng);
-        g = &h->graphs.back();
-      }
-      HIPCHK(h, hipGraphLaunch(g->exec, h->stream));
-      ln.parity = g->parity_out;
-    }
-    h->sweep_parity = ln.parity;
-  } else {
-    // Environments are independent: walk them in cache-sized groups, neighbouring groups on different
-    // streams so that one group's field solves and kernel tails hide under the other's sweeps.
-    const int S = (int)h->wstreams.size();
-    const int ngroups = (E + G - 1) / G;
-    HIPCHK(h, hipEventRecord(h->fork_ev, h->stream));
-    for (int w = 0; w < S; ++w) HIPCHK(h, hipStreamWaitEvent(h->wstreams[w], h->fork_ev, 0));
-    int parity = h->sweep_parity;
-    if (h->group_major) {
-      for (int g = 0; g < ngroups; ++g) {
-        Lane ln{h->wstreams[g % S], g * G, (g + 1) * G <= E ? G : E - g * G, h->sweep_parity};
-        for (int s = 0; s < nsteps; ++s) one_step(ln, s > 0 || q1_ready);
-        parity = ln.parity;
-      }
-    } else {
-      for (int s = 0; s < nsteps; ++s)
-        for (int g = 0; g < ngroups; ++g) {
-          Lane ln{h->wstreams[g % S], g * G, (g + 1) * G <= E ? G : E - g * G, (h->sweep_parity + 3 * s) & 1};
-          one_step(ln, s > 0 || q1_ready);
-          parity = ln.parity;
-        }
-    }
-    h->sweep_parity = parity;
-    for (int w = 0; w < S; ++w) {
-      HIPCHK(h, hipEventRecord(h->join_ev[w], h->wstreams[w]));
-      HIPCHK(h, hipStreamWaitEvent(h->stream, h->join_ev[w], 0));
-    }
-  }
-  if (nsteps > 0) h->q1_ready = true;
+  const double* ext;
+  int rc = stage_ext(h, E_ext, mem_kind, &ext);
+  if (rc) return rc;
+  for (int s = 0; s < nsteps; ++s) run_stages(h, 1, 3, ext);
   HIPCHK(h, hipGetLastError());
   return PIC_OK;
 }
@@ -834,7 +727,7 @@ int pic_get_particles(pic_handle* h, void* x, void* v, int mem_kind) {
   if (!h) return PIC_EINVAL;
   HIPCHK(h, hipSetDevice(h->cfg.device_id));
   int rc = PIC_OK;
-  if (x) rc = download(h, x, h->x, mem_kind);
+  if (x) rc = download_positions(h, x, h->x, mem_kind);
   if (!rc && v) rc = download(h, v, h->v, mem_kind);
   if (rc) return rc;
   HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -929,26 +822,35 @@ int pic_get_cic(pic_handle* h, int env, int64_t* indx_l, int64_t* indx_r, double
   return PIC_OK;
 }
 
+// deposit of the positions in h->scratch into the probe accumulator, then one solve with `ext` added
+static int probe_solve(pic_handle* h, const double* E_ext, bool want_phi) {
+  const size_t gbytes = (size_t)h->cfg.num_envs * h->cfg.Ng * sizeof(double);
+  const double* ext = nullptr;
+  if (E_ext) {
+    HIPCHK(h, hipMemcpyAsync(h->probe_ext, E_ext, gbytes, hipMemcpyHostToDevice, h->stream));
+    ext = h->probe_ext;
+  }
+  HIPCHK(h, hipMemsetAsync(h->probe_acc, 0, gbytes, h->stream));
+  launch_sweep(h, ST_PROBE, h->scratch, h->scratch, 0, 0, 0, -1, nullptr, h->probe_acc, nullptr);
+  SolveIO o{};
+  o.acc = h->probe_acc; o.ext = ext; o.n = h->aux_n; o.E = h->aux_E; o.PEr = h->aux_pe;
+  if (want_phi) o.phi = h->aux_phi;
+  launch_solve(h, o);
+  HIPCHK(h, hipGetLastError());
+  return PIC_OK;
+}
+
 int pic_eval_field(pic_handle* h, const void* x, int mem_kind, const double* E_ext, double* n, double* E_mesh,
                    double* half_sum_E2_dx) {
   if (!h || !x) return fail(h, PIC_EINVAL, "pic_eval_field: null argument");
   HIPCHK(h, hipSetDevice(h->cfg.device_id));
   int rc = ensure_scratch(h);
   if (rc) return rc;
-  rc = upload(h, h->scratch, x, mem_kind);
+  rc = upload_positions(h, h->scratch, x, mem_kind);
+  if (rc) return rc;
+  rc = probe_solve(h, E_ext, false);
   if (rc) return rc;
   const size_t gbytes = (size_t)h->cfg.num_envs * h->cfg.Ng * sizeof(double);
-  const double* ext = nullptr;
-  if (E_ext) {
-    HIPCHK(h, hipMemcpyAsync(h->ext, E_ext, gbytes, hipMemcpyHostToDevice, h->stream));
-    ext = h->ext;
-  }
-  Lane ln = whole(h);
-  launch_sweep(h, ln, ST_PROBE, h->scratch, h->scratch, 0, 0, 0);
-  SolveOut o;
-  o.ext = ext; o.n = h->aux_n; o.E = h->aux_E; o.PEr = h->aux_pe;
-  launch_solve(h, ln, o);
-  HIPCHK(h, hipGetLastError());
   if (n) HIPCHK(h, hipMemcpyAsync(n, h->aux_n, gbytes, hipMemcpyDeviceToHost, h->stream));
   if (E_mesh) HIPCHK(h, hipMemcpyAsync(E_mesh, h->aux_E, gbytes, hipMemcpyDeviceToHost, h->stream));
   if (half_sum_E2_dx)
@@ -963,23 +865,13 @@ int pic_compute_E(pic_handle* h, const void* x, int mem_kind, const double* E_ex
   HIPCHK(h, hipSetDevice(h->cfg.device_id));
   int rc = ensure_scratch(h);
   if (rc) return rc;
-  rc = upload(h, h->scratch, x, mem_kind);
+  rc = upload_positions(h, h->scratch, x, mem_kind);
   if (rc) return rc;
   const int E_ = h->cfg.num_envs;
   const long long N = h->cfg.N;
   const size_t gbytes = (size_t)E_ * h->cfg.Ng * sizeof(double);
-  if (!h->aux_phi) HIPCHK(h, hipMalloc((void**)&h->aux_phi, gbytes));
-  const double* ext = nullptr;
-  if (E_ext) {
-    HIPCHK(h, hipMemcpyAsync(h->ext, E_ext, gbytes, hipMemcpyHostToDevice, h->stream));
-    ext = h->ext;
-  }
-  Lane ln = whole(h);
-  launch_sweep(h, ln, ST_PROBE, h->scratch, h->scratch, 0, 0, 0);
-  SolveOut o;
-  o.ext = ext; o.n = h->aux_n; o.E = h->aux_E; o.phi = h->aux_phi; o.PEr = h->aux_pe;
-  launch_solve(h, ln, o);
-  HIPCHK(h, hipGetLastError());
+  rc = probe_solve(h, E_ext, true);
+  if (rc) return rc;
   if (n) HIPCHK(h, hipMemcpyAsync(n, h->aux_n, gbytes, hipMemcpyDeviceToHost, h->stream));
   if (E_mesh) HIPCHK(h, hipMemcpyAsync(E_mesh, h->aux_E, gbytes, hipMemcpyDeviceToHost, h->stream));
   if (phi_mesh) HIPCHK(h, hipMemcpyAsync(phi_mesh, h->aux_phi, gbytes, hipMemcpyDeviceToHost, h->stream));
@@ -1021,13 +913,10 @@ int pic_solve_poisson(pic_handle* h, const double* rhs, double* phi, double* E_m
   if (!h || !rhs) return fail(h, PIC_EINVAL, "pic_solve_poisson: null argument");
   HIPCHK(h, hipSetDevice(h->cfg.device_id));
   const size_t gbytes = (size_t)h->cfg.num_envs * h->cfg.Ng * sizeof(double);
-  if (!h->aux_phi) HIPCHK(h, hipMalloc((void**)&h->aux_phi, gbytes));
-  // aux_n doubles as the one-row "slab" holding the right-hand side; the solve reads it before it writes n
   HIPCHK(h, hipMemcpyAsync(h->aux_n, rhs, gbytes, hipMemcpyHostToDevice, h->stream));
-  Lane ln = whole(h);
-  SolveOut o;
-  o.slab = h->aux_n; o.E = h->aux_E; o.phi = h->aux_phi;
-  launch_solve(h, ln, o, nullptr, 1);
+  SolveIO o{};
+  o.rhs = h->aux_n; o.E = h->aux_E; o.phi = h->aux_phi;
+  launch_solve(h, o);
   HIPCHK(h, hipGetLastError());
   if (phi) HIPCHK(h, hipMemcpyAsync(phi, h->aux_phi, gbytes, hipMemcpyDeviceToHost, h->stream));
   if (E_mesh) HIPCHK(h, hipMemcpyAsync(E_mesh, h->aux_E, gbytes, hipMemcpyDeviceToHost, h->stream));
@@ -1097,20 +986,20 @@ int pic_reset_sampled(pic_handle* h, int kind, double a, double v0, double sigma
   if (!h || (kind != 0 && kind != 1) || !(sigma > 0) || (kind == 1 && !(a >= 0)))
     return fail(h, PIC_EINVAL, "pic_reset_sampled: kind must be 0 (two-stream) or 1 (bump-on-tail), sigma > 0, a >= 0");
   HIPCHK(h, hipSetDevice(h->cfg.device_id));
-  long long gx = (h->cfg.N + BLOCK - 1) / BLOCK;
-  if (gx > 2048) gx = 2048;
-  dim3 grid((unsigned)gx, h->cfg.num_envs);
-  if (h->cfg.particle_dtype == PIC_F64)
-    hipLaunchKernelGGL(sample_kernel<double>, grid, dim3(BLOCK), 0, h->stream, (double*)h->x, (double*)h->v, h->cfg.N,
+  const dim3 grid = aux_grid(h, h->cfg.num_envs, 2048);
+  if (h->fmt == FMT_F64)
+    hipLaunchKernelGGL(sample_kernel<PosF64>, grid, dim3(BLOCK), 0, h->stream, (double*)h->x, (double*)h->v, h->cfg.N,
+                       h->ld, kind, a, v0, sigma, A, n_mode, h->cfg.L, (unsigned long long)seed, h->cfg.env_index_base);
+  else if (h->fmt == FMT_F32)
+    hipLaunchKernelGGL(sample_kernel<PosF32>, grid, dim3(BLOCK), 0, h->stream, (float*)h->x, (float*)h->v, h->cfg.N,
                        h->ld, kind, a, v0, sigma, A, n_mode, h->cfg.L, (unsigned long long)seed, h->cfg.env_index_base);
   else
-    hipLaunchKernelGGL(sample_kernel<float>, grid, dim3(BLOCK), 0, h->stream, (float*)h->x, (float*)h->v, h->cfg.N,
+    hipLaunchKernelGGL(sample_kernel<PosU32>, grid, dim3(BLOCK), 0, h->stream, (unsigned*)h->x, (float*)h->v, h->cfg.N,
                        h->ld, kind, a, v0, sigma, A, n_mode, h->cfg.L, (unsigned long long)seed, h->cfg.env_index_base);
   HIPCHK(h, hipGetLastError());
   HIPCHK(h, hipMemsetAsync(h->bad, 0, sizeof(unsigned long long), h->stream));
   h->has_state = true;
-  h->q1_ready = false;
-  return refresh_fields(h);
+  return refresh_fields(h);      // a reset abandons an open staged step and any cached deposit
 }
 
 int pic_phase_histogram(pic_handle* h, int nbins, double vmin, double vmax, uint32_t* counts) {
@@ -1122,15 +1011,16 @@ int pic_phase_histogram(pic_handle* h, int nbins, double vmin, double vmax, uint
   unsigned* d = nullptr;
   HIPCHK(h, hipMalloc((void**)&d, nb));
   hipError_t e = hipMemsetAsync(d, 0, nb, h->stream);
-  long long gx = (h->cfg.N + BLOCK - 1) / BLOCK;
-  if (gx > 2048) gx = 2048;
-  dim3 grid((unsigned)gx, h->cfg.num_envs);
+  const dim3 grid = aux_grid(h, h->cfg.num_envs, 2048);
   if (e == hipSuccess) {
-    if (h->cfg.particle_dtype == PIC_F64)
-      hipLaunchKernelGGL(phase_hist_kernel<double>, grid, dim3(BLOCK), 0, h->stream, (const double*)h->x,
+    if (h->fmt == FMT_F64)
+      hipLaunchKernelGGL(phase_hist_kernel<PosF64>, grid, dim3(BLOCK), 0, h->stream, (const double*)h->x,
                          (const double*)h->v, d, h->cfg.N, h->ld, nbins, h->cfg.L, vmin, vmax);
+    else if (h->fmt == FMT_F32)
+      hipLaunchKernelGGL(phase_hist_kernel<PosF32>, grid, dim3(BLOCK), 0, h->stream, (const float*)h->x,
+                         (const float*)h->v, d, h->cfg.N, h->ld, nbins, h->cfg.L, vmin, vmax);
     else
-      hipLaunchKernelGGL(phase_hist_kernel<float>, grid, dim3(BLOCK), 0, h->stream, (const float*)h->x,
+      hipLaunchKernelGGL(phase_hist_kernel<PosU32>, grid, dim3(BLOCK), 0, h->stream, (const unsigned*)h->x,
                          (const float*)h->v, d, h->cfg.N, h->ld, nbins, h->cfg.L, vmin, vmax);
     e = hipGetLastError();
   }
@@ -1144,9 +1034,7 @@ int pic_phase_histogram(pic_handle* h, int nbins, double vmin, double vmax, uint
 int pic_stream_probe(pic_handle* h, int repeats, double* gbytes_per_s) {
   if (!h || !gbytes_per_s || repeats < 1) return fail(h, PIC_EINVAL, "pic_stream_probe: bad argument");
   HIPCHK(h, hipSetDevice(h->cfg.device_id));
-  size_t pbytes = (size_t)h->cfg.num_envs * h->ld * h->esz;
-  if (const char* mb = getenv("PICSTEP_PROBE_MB")) pbytes = (size_t)atoll(mb) << 20;   // experiment knobs
-  const int work = getenv("PICSTEP_PROBE_WORK") ? atoi(getenv("PICSTEP_PROBE_WORK")) : 0;
+  const size_t pbytes = (size_t)h->cfg.num_envs * h->ld * h->esz;
   void *a = nullptr, *b = nullptr;
   HIPCHK(h, hipMalloc(&a, pbytes));
   if (hipMalloc(&b, pbytes) != hipSuccess) { hipFree(a); return fail(h, PIC_ENOMEM, "pic_stream_probe: hipMalloc"); }
@@ -1159,10 +1047,10 @@ int pic_stream_probe(pic_handle* h, int repeats, double* gbytes_per_s) {
   hipEvent_t e0, e1;
   hipEventCreate(&e0);
   hipEventCreate(&e1);
-  hipLaunchKernelGGL(stream_probe_kernel, dim3((unsigned)nb), dim3(BLOCK), 0, h->stream, (double2*)a, (double2*)b, n2, chunk2, 1.0, 1, work);
+  hipLaunchKernelGGL(stream_probe_kernel, dim3((unsigned)nb), dim3(BLOCK), 0, h->stream, (double2*)a, (double2*)b, n2, chunk2, 1.0, 1);
   hipEventRecord(e0, h->stream);
   for (int r = 0; r < repeats; ++r)
-    hipLaunchKernelGGL(stream_probe_kernel, dim3((unsigned)nb), dim3(BLOCK), 0, h->stream, (double2*)a, (double2*)b, n2, chunk2, 1.0, r & 1, work);
+    hipLaunchKernelGGL(stream_probe_kernel, dim3((unsigned)nb), dim3(BLOCK), 0, h->stream, (double2*)a, (double2*)b, n2, chunk2, 1.0, r & 1);
   hipEventRecord(e1, h->stream);
   hipError_t e = hipEventSynchronize(e1);
   float ms = 0.f;
@@ -1205,22 +1093,10 @@ int pic_profile_read(pic_handle* h, double* ms_sum, int64_t* launches) {
 int pic_bad_count(pic_handle* h, int64_t* count) {
   if (!h || !count) return PIC_EINVAL;
   HIPCHK(h, hipSetDevice(h->cfg.device_id));
-  unsigned long long c[4] = {0, 0, 0, 0};
-  HIPCHK(h, hipMemcpyAsync(c, h->bad, sizeof(c), hipMemcpyDeviceToHost, h->stream));
+  unsigned long long c = 0;
+  HIPCHK(h, hipMemcpyAsync(&c, h->bad, sizeof(c), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
-  *count = (int64_t)c[0];
-#ifdef PIC_EXP_STAMPB
-  if (c[3]) {
-    const double nw = (double)(c[3] & 0xffffffffull);
-    fprintf(stderr, "[stampB] sweep C, late workgroups, per wave: zero-LDS %.2f us  field-tile load %.2f us  barrier %.2f us  loop %.2f us  straggler wait %.2f us  (waves=%.0f)\n",
-            0.01 * (double)(c[1] >> 32) / nw, 0.01 * (double)(c[1] & 0xffffffffull) / nw, 0.01 * (double)(c[2] >> 32) / nw,
-            0.01 * (double)(c[2] & 0xffffffffull) / nw, 0.01 * (double)(c[3] >> 32) / nw, nw);
-  }
-#endif
-#ifdef PIC_EXP_STAMP
-  if (c[3]) fprintf(stderr, "[stamp] sweep C wave0/block: iterations=%llu  mem-wait %.3f us/iter  push+store-issue %.3f us/iter\n",
-                    c[3], 0.01 * (double)c[1] / (double)c[3], 0.01 * (double)c[2] / (double)c[3]);
-#endif
+  *count = (int64_t)c;
   return PIC_OK;
 }
 

@@ -21,7 +21,7 @@ class _DeviceView:
 class BatchedPIC:
     def __init__(self, num_envs: int, N: int, N_mesh: int, n0: float = 1.0, L: float = 50.0, dt: float = 0.1,
                  gamma: float = 5.0, interpol: str = "CIC", device: int = 0, dtype="float64", accum_dtype=None,
-                 blocks_per_env: int = 0, verbose: bool = False, env_index_base: int = 0):
+                 blocks_per_env: int = 0, verbose: bool = False, env_index_base: int = 0, position_dtype=None):
         self.num_envs, self.N, self.N_mesh = int(num_envs), int(N), int(N_mesh)
         self.n0, self.L, self.gamma, self.interpol = n0, L, gamma, interpol
         self.dx = L / N_mesh
@@ -34,7 +34,8 @@ class BatchedPIC:
         self.device = device
         self.dtype = np.dtype(dtype)
         self._h = _abi.Handle(self.N, self.N_mesh, self.num_envs, L, n0, self.dt, gamma, self.dtype, accum_dtype,
-                              interpol, device, blocks_per_env, env_index_base)
+                              interpol, device, blocks_per_env, env_index_base, position_dtype)
+        self.fixed_positions = self._h.fixed_positions
 
     # reset(x0, v0): x0, v0 are [num_envs, N] with any velocity perturbation already applied
     def reset(self, x0, v0):
@@ -201,7 +202,9 @@ class BatchedPIC:
     def torch_views(self):
         """Zero-copy torch tensors over the device state: x, v [num_envs, N] (strided), n, E_mesh,
         phi [num_envs, Ng], KE, PE, PE_reward [num_envs].  Call sync() before reading them on
-        another stream."""
+        another stream.  A write to x or v must be followed by invalidate() or refresh().
+        With position_dtype="fixed32" the zero-copy position view is `x_fixed` (int32 bit pattern of the
+        uint32 u, x = u L / 2^32) and `x` is a float64 COPY computed from it."""
         import torch
 
         p = self._h.device_ptrs()
@@ -210,13 +213,25 @@ class BatchedPIC:
         dev = f"cuda:{self.device}"
         out = {}
         for k in ("x", "v"):
-            view = _DeviceView(p[k], (self.num_envs, self.N), ts, (p["ld"] * isz, isz))
+            t = "<i4" if (k == "x" and self.fixed_positions) else ts
+            view = _DeviceView(p[k], (self.num_envs, self.N), t, (p["ld"] * isz, isz))
             out[k] = torch.as_tensor(view, device=dev)
+        if self.fixed_positions:
+            out["x_fixed"] = out["x"]
+            out["x"] = (out["x_fixed"].to(torch.int64) & 0xFFFFFFFF).to(torch.float64) * (self.L / 2.0 ** 32)
         for k in ("n", "E_mesh", "phi"):
             out[k] = torch.as_tensor(_DeviceView(p[k], (self.num_envs, self.N_mesh), "<f8"), device=dev)
         for k in ("KE", "PE", "PE_reward"):
             out[k] = torch.as_tensor(_DeviceView(p[k], (self.num_envs,), "<f8"), device=dev)
         return out
+
+    def invalidate(self):
+        """After a write to x / v through `torch_views()`: drop the cached first deposit of the next step."""
+        self._h.invalidate()
+
+    def refresh(self):
+        """update_density + update_E_field on the current particles (also valid after a write through the views)."""
+        self._h.refresh()
 
     def close(self):
         self._h.close()

@@ -34,3 +34,20 @@ def circ_err(xa, xb, L):
     """max distance on the circle of circumference L (x=0 and x=L-eps are neighbours)."""
     d = np.abs(np.asarray(xa, dtype=float).ravel() - np.asarray(xb, dtype=float).ravel())
     return float(np.max(np.minimum(d, L - d)))
+
+
+# Measured error margins of the GPU tests: every call appends "name: value" to gpurun_out/measured_r2.json on the
+# box (gpurun merges that directory back), so that the asserted bounds can be quoted against what was measured.
+_MEASURED = {}
+
+
+def record_measure(name, value):
+    import json
+    _MEASURED[name] = float(value)
+    out = os.path.join(ROOT, "gpurun_out")
+    try:
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, "measured_r2.json"), "w") as f:
+            json.dump(_MEASURED, f, indent=1, sort_keys=True)
+    except OSError:
+        pass
