@@ -237,9 +237,15 @@ def main():
         esz = 8 if args.dtype == "float64" else 4
         for k, (ms, cnt) in prof.items():
             kernels[k] = {"avg_ms": ms / cnt, "launches": cnt}
-        dom = max((k for k in prof if k in SWEEP_WORDS), key=lambda k: prof[k][0])
+        if "resident" in prof:
+            # small environments: the whole call is one launch that reads and writes the particles once and keeps
+            # them in registers in between; the step is bound by latency and VALU issue, not by HBM
+            dom = "resident"
+            alg_bytes = 4 * esz * N * E
+        else:
+            dom = max((k for k in prof if k in SWEEP_WORDS), key=lambda k: prof[k][0])
+            alg_bytes = SWEEP_WORDS[dom] * esz * N * E
         avg_s = prof[dom][0] / prof[dom][1] * 1e-3
-        alg_bytes = SWEEP_WORDS[dom] * esz * N * E
         ach = alg_bytes / avg_s / 1e9
         traffic, traffic_source = pmc_traffic(dom, args, E, N, Ng)
         roof = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -259,7 +265,7 @@ def main():
                                f"bump-on-tail, N={N}, Ng={Ng}, {E} envs per GPU, {args.dtype}"
                                f"{' (fixed-point positions)' if args.positions == 'fixed32' else ''}, "
                                "no control (E_ext = None), Yoshida-4 step = PIC.update_state",
-                   "envs_per_gpu": E, "particles_per_env": N, "mesh": Ng, "dt": env.dt,
+                   "envs_per_gpu": E, "particles_per_env": N, "mesh": Ng, "dt": env.dt, "schedule": env._h.schedule(),
                    "sharding": f"{world} x {E} envs, all-gather of returns only"},
         # whole-step fractions of the 8 TB/s peak: on the bytes the schedule really moves (12 words per particle-step)
         # and on SURVEY 8d's algorithmic count (14 words; > the first because sweep A's read is not made at all)

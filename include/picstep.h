@@ -63,7 +63,11 @@ typedef struct pic_config {
                               the way and make a step bitwise reproducible                        */
   int32_t interpol;        /* PIC_CIC | PIC_TSC                                           */
   int32_t device_id;       /* HIP device ordinal                                          */
-  int32_t blocks_per_env;  /* 0 = choose; workgroups streaming one environment per sweep  */
+  int32_t blocks_per_env;  /* 0 = choose the schedule: environments of up to 8192 particles are stepped RESIDENT (all
+                              sub-stages and steps of a pic_step call inside one workgroup and one launch), larger ones
+                              by streaming sweeps over a chosen number of workgroups; > 0 = streaming sweeps with this
+                              many workgroups per environment; -1 = resident, or EINVAL where it does not apply.
+                              Particles and fields do not depend on the choice, bit for bit                       */
   int32_t env_index_base;  /* global index of environment 0 of this handle (0 for a single handle): keys the device
                               sampler, so that a sharded ensemble does not depend on the number of ranks           */
   int32_t position_dtype;  /* PIC_POS_FLOAT | PIC_POS_FIXED32 (needs particle_dtype PIC_F32).  Fixed-point positions
@@ -208,6 +212,9 @@ int pic_stream_probe(pic_handle* h, int repeats, double* gbytes_per_s);
  * device-pointer inputs/outputs (pic_step, pic_step_actions, pic_get_modes, pic_device_ptrs views) a
  * control loop then stays stream-ordered with the caller's kernels and needs no host synchronisation. */
 int pic_set_stream(pic_handle* h, void* hip_stream);
+
+/* 1 if pic_step runs the resident schedule on this handle, 0 for streaming sweeps (see blocks_per_env). */
+int pic_schedule(pic_handle* h);
 
 int pic_sync(pic_handle* h);
 /* Number of particle positions found non-finite or out of range by the last sweeps (0 = healthy). */

@@ -22,7 +22,7 @@ ACCUMULATORS = {None: PIC_ACC_AUTO, "auto": PIC_ACC_AUTO, "fix64": PIC_ACC_FIX64
                 "packed": PIC_ACC_PACKED, "float64": PIC_ACC_F64}
 POSITION_FORMATS = {None: PIC_POS_FLOAT, "float": PIC_POS_FLOAT, "fixed32": PIC_POS_FIXED32}
 
-KIND_NAMES = ("sweep_A", "sweep_B", "sweep_C", "sweep_D", "field_solve", "sweep_aux", "", "")
+KIND_NAMES = ("sweep_A", "sweep_B", "sweep_C", "sweep_D", "field_solve", "sweep_aux", "resident", "")
 
 
 class PicConfig(C.Structure):
@@ -71,6 +71,7 @@ SIGNATURES = {
     "pic_phase_histogram": [_vp, C.c_int, C.c_double, C.c_double, _vp],
     "pic_stream_probe": [_vp, C.c_int, _dp],
     "pic_set_stream": [_vp, _vp],
+    "pic_schedule": [_vp],
     "pic_sync": [_vp],
     "pic_bad_count": [_vp, _i64p],
     "pic_last_error": [_vp],
@@ -219,6 +220,10 @@ class Handle:
     def sync(self):
         self._chk(self.lib.pic_sync(self._h))
 
+    def schedule(self):
+        """'resident' (one launch per pic_step call, small environments) or 'streaming' (sweeps)."""
+        return "resident" if self.lib.pic_schedule(self._h) == 1 else "streaming"
+
     def particles(self):
         x = np.empty((self.num_envs, self.N), dtype=self.dtype)
         v = np.empty_like(x)
@@ -318,7 +323,7 @@ class Handle:
         ms = (C.c_double * 8)()
         cnt = (C.c_int64 * 8)()
         self._chk(self.lib.pic_profile_read(self._h, ms, cnt))
-        return {KIND_NAMES[i]: (ms[i], cnt[i]) for i in range(6) if cnt[i]}
+        return {KIND_NAMES[i]: (ms[i], cnt[i]) for i in range(7) if cnt[i]}
 
     def set_actuator(self, basis_cos, basis_sin):
         bc = np.ascontiguousarray(basis_cos, dtype=np.float64)

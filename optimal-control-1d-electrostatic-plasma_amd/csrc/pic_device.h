@@ -44,6 +44,7 @@ struct SweepArgs {
   double c_prev, c_cur, d_cur, c_next;
   double scale, n0;   // density scale n0 L / N / dx and mean density, for the in-prologue field solve
   double to_units;    // 2^32 / L: fixed-point position units per length (PosU32)
+  double N_over_L;    // PE = PE_reward N / L (util.py:130)
 };
 
 struct SolveArgs {
@@ -108,13 +109,21 @@ __device__ __noinline__ T wrap_periodic_far(T q, T L) {   // |q| beyond one box 
 }
 
 template <typename T>
-__device__ __forceinline__ T wrap_periodic(T q, T L) {
+__device__ __forceinline__ T wrap_periodic(T q, T L, unsigned& bad) {
   // the three near ranges as selects (a particle moves a small fraction of L per sub-stage)
   T up = q + L;                       // q in [-L, 0)
   up = (up >= L) ? T(0) : up;         // tiny negative q: q + L rounds to L, the second mod gives 0
   T r = (q < T(0)) ? up : q;
   r = (q >= L) ? q - L : r;           // q in [L, 2L): exact (Sterbenz)
-  if (__builtin_expect(!(q >= -L && q < L + L), 0)) r = wrap_periodic_far(q, L);
+  // For q in [-L, 2L) r now lies in [0, L).  One range test therefore catches both a position further away
+  // (fmod path) and a NaN / inf one (counted, parked on node 0, never used as an index).
+  if (__builtin_expect(!(r >= T(0) && r < L), 0)) {
+    r = wrap_periodic_far(q, L);
+    if (!(r >= T(0) && r < L)) {
+      bad += 1u;
+      r = T(0);
+    }
+  }
   return r;
 }
 
@@ -158,11 +167,7 @@ __device__ __forceinline__ void locate(typename P::X q, const Consts<P>& k, type
     }
   } else {
     frac = 0u;
-    xw = wrap_periodic(q, k.L);
-    if (!(xw >= T(0) && xw < k.L)) {   // NaN / inf position: count it, park it on node 0, never index with it
-      bad += 1u;
-      xw = T(0);
-    }
+    xw = wrap_periodic(q, k.L, bad);
     T jf = floor(div_dx(xw, k.dx, k.rdx));
     j = (int)jf;
     // j == Ng happens when xw/dx rounds up to Ng (undefined in the reference: bincount grows a bin and

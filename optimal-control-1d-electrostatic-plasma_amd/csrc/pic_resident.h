@@ -1,0 +1,235 @@
+// pic_resident.h -- resident_kernel<P, A, SHAPE, PPT, NW>: whole environment steps inside ONE workgroup.
+//
+// The reference's own workload is many small environments (N = 5000, Ng = 250: run_wo_oc.py:33-34, the RL
+// trainers).  There a step of the streaming schedule is four dependent launches of a few microseconds each and
+// most of that is latency (accumulator round trips, kernel boundaries).  When an environment's particles fit
+// the registers of one workgroup (N <= 64 NW PPT, up to 8192), this kernel keeps them there for all `nsteps` steps
+// of a pic_step call: the meshes live in LDS, the field solves are workgroup scans, nothing crosses a kernel
+// boundary and nothing but the final particles, fields and per-step energies goes to HBM.
+//
+// Arithmetic is the streaming path's, helper by helper (locate, gather_field, drift, deposit, mesh_node_sum,
+// scan_gradient; the gather re-uses the cell and weights the previous deposit located instead of locating the same
+// position again), and the deposits are the same integer sums, so particles and fields come out bit for bit as
+// from the sweeps (tests/test_gpu_resident.py).  Only KE, a float64 sum whose order follows the launch geometry,
+// may differ in its last bits.
+#pragma once
+#include "pic_device.h"
+#include "pic_sweep.h"
+
+namespace {
+
+struct ResidentIO {
+  const double* ext;       // [env][Ng] external field of the force evaluations, or null
+  double *n, *E, *phi;     // [env][Ng] post-step refresh of the LAST step (pic.py:145-146)
+  double *KE, *PE, *PEr;   // [env]
+  double* hist;            // [nsteps][3][env] KE, PE, PE_reward after every step, or null
+  unsigned long long* bad;
+  int nsteps;
+  int num_envs;
+  double c1, c2, d1, d2;   // Yoshida-4 (integration.py:62-69): c = (c1, c2, c2, c1), d = (0, d1, d2, d1)
+};
+
+// field tile Es (gather layout: Ng + 2 slots, OFF for TSC) from the LDS mesh `acc_all`; sb: Ng doubles of scratch
+template <typename T, typename A, int SHAPE, int NW>
+__device__ __forceinline__ void resident_field(const A* __restrict__ acc_all, int R, int stride, const double* __restrict__ ext,
+                                               int Ng, int fg, double scale, double n0, double dx, double* __restrict__ sb,
+                                               double* __restrict__ ws, T* __restrict__ Es) {
+  constexpr int NT = NW * 64;
+  constexpr int OFF = (SHAPE == PIC_TSC) ? 1 : 0;
+  const int tid = threadIdx.x;
+  const double unit = ldexp(1.0, -fg);
+  for (int j = tid; j < Ng; j += NT)
+    sb[j] = ((double)mesh_node_sum<A, SHAPE>(acc_all, R, stride, Ng, fg, j) * unit) * scale - n0;
+  __syncthreads();
+  const double gmean = scan_gradient<NW>(sb, Ng, dx, ws);
+  for (int i = tid; i < Ng + 2; i += NT) {
+    int node = i - OFF;
+    node = node < 0 ? node + Ng : (node >= Ng ? node - Ng : node);
+    const double gp = sb[node] - gmean;
+    const double gm = sb[node == 0 ? Ng - 1 : node - 1] - gmean;
+    double E = -0.5 * (gp + gm);
+    if (ext) E += ext[node];
+    Es[i] = (T)E;
+  }
+  __syncthreads();
+}
+
+template <typename P, typename A, int SHAPE, int PPT, int NW>
+__global__ __launch_bounds__(NW * 64) void resident_kernel(typename P::X* __restrict__ x, typename P::V* __restrict__ v,
+                                                           ResidentIO io, SweepArgs a) {
+  constexpr int NT = NW * 64;
+  using T = typename P::W;
+  using X = typename P::X;
+  using V = typename P::V;
+
+  // LDS: [R meshes: accA][R meshes: accB][sb: Ng doubles][se: Ng doubles][field tile Es]
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  const int Ng = a.Ng;
+  const int stride = Ng + 2;
+  const int R = a.R;
+  A* accA = reinterpret_cast<A*>(smem_raw);
+  A* accB = accA + (size_t)R * stride;
+  double* sb = reinterpret_cast<double*>(accB + (size_t)R * stride);
+  double* se = sb + Ng;
+  T* Es = reinterpret_cast<T*>(se + Ng);
+  __shared__ double ws[NW];
+
+  const int tid = threadIdx.x;
+  const int env = blockIdx.x;
+  const int rep = (tid >> 6) & (R - 1);
+  const Consts<P> k(a);
+  const T c1 = (T)io.c1, c2 = (T)io.c2, d1 = (T)io.d1, d2 = (T)io.d2;
+  X* xe = x + (size_t)env * a.ld;
+  V* ve = v + (size_t)env * a.ld;
+  const double* ext = io.ext ? io.ext + (size_t)env * Ng : nullptr;
+  const size_t row = (size_t)env * Ng;
+
+  // particle tid + s NT lives in slot s of lane tid
+  X xs[PPT];
+  V vs[PPT];
+#pragma unroll
+  for (int s = 0; s < PPT; ++s) {
+    const long long i = (long long)s * NT + tid;
+    xs[s] = i < a.N ? xe[i] : X(0);
+    vs[s] = i < a.N ? ve[i] : V(0);
+  }
+  unsigned bad = 0u;
+
+  // Where a sub-stage deposits a particle is where the next one gathers its field, so cell and weights of that
+  // position are carried in registers from one sub-stage to the next: one locate per sub-stage instead of two.
+  int js[PPT];
+  T wgt[PPT][SHAPE == PIC_TSC ? 3 : 2];
+
+  // deposit of the first drift position q1 = x + (c1 v) dt (integration.py:42 with d1 = 0) into accA
+  for (int i = tid; i < 2 * R * stride; i += NT) accA[i] = A{};
+  __syncthreads();
+#pragma unroll
+  for (int s = 0; s < PPT; ++s) {
+    js[s] = 0;
+    if ((long long)s * NT + tid < a.N) {
+      T w[3];
+      X xw;
+      int j;
+      unsigned frac;
+      const X q = drift<P>(xs[s], vs[s], c1, k, bad);
+      locate<P, SHAPE>(q, k, xw, j, w, frac, bad);
+      deposit<A, P, SHAPE>(accA + (size_t)rep * stride, j, w, frac, k.magic);
+      js[s] = j;
+      wgt[s][0] = w[0]; wgt[s][1] = w[1];
+      if (SHAPE == PIC_TSC) wgt[s][SHAPE == PIC_TSC ? 2 : 0] = w[2];
+    }
+  }
+  __syncthreads();
+
+  for (int step = 0; step < io.nsteps; ++step) {
+    double ke = 0.0;
+    for (int st = ST_B; st <= ST_D; ++st) {
+      // sub-stage st reads the field of the deposit in `in` and deposits into `out` (D: also the next q1 into `in`)
+      A* in = (st == ST_C) ? accB : accA;
+      A* out = (st == ST_C) ? accA : accB;
+      resident_field<T, A, SHAPE, NW>(in, R, stride, ext, Ng, a.fg, a.scale, a.n0, a.dx, sb, ws, Es);
+      for (int i = tid; i < R * stride; i += NT) out[i] = A{};
+      if (st == ST_D) for (int i = tid; i < R * stride; i += NT) in[i] = A{};
+      __syncthreads();
+      // Yoshida coefficients of this sub-stage (integration.py:62-69): (c, d) = (c2, d1), (c3, d2), (c4, d3)
+      const T c_cur = (st == ST_D) ? c1 : c2;
+      const T d_cur = (st == ST_C) ? d2 : d1;
+      A* acc = out + (size_t)rep * stride;
+      A* acc2 = in + (size_t)rep * stride;
+#pragma unroll
+      for (int s = 0; s < PPT; ++s) {
+        if ((long long)s * NT + tid < a.N) {
+          T w[3];
+          X xw;
+          int j = js[s];
+          unsigned frac;
+          X q = xs[s];
+          V p = vs[s];
+          if (st == ST_B) q = drift<P>(q, p, c1, k, bad);         // q1 again (it is never stored)
+          w[0] = wgt[s][0]; w[1] = wgt[s][1];
+          w[2] = (SHAPE == PIC_TSC) ? wgt[s][SHAPE == PIC_TSC ? 2 : 0] : T(0);
+          const T E = gather_field<T, SHAPE>(Es, j, w);           // util.py:105 / pic.py:120, at the carried cell / weights
+          p = p + (V)((d_cur * (-E)) * k.dt);                     // integration.py:32, pic.py:127
+          q = drift<P>(q, p, c_cur, k, bad);                      // integration.py:42
+          locate<P, SHAPE>(q, k, xw, j, w, frac, bad);
+          deposit<A, P, SHAPE>(acc, j, w, frac, k.magic);
+          if (st == ST_D) {
+            q = xw;                                               // pic.py:139 (+ util.py:51)
+            ke += (double)p * (double)p;
+            const X qn = drift<P>(q, p, c1, k, bad);              // next step's q1
+            X xn;
+            locate<P, SHAPE>(qn, k, xn, j, w, frac, bad);
+            deposit<A, P, SHAPE>(acc2, j, w, frac, k.magic);
+          }
+          js[s] = j;
+          wgt[s][0] = w[0]; wgt[s][1] = w[1];
+          if (SHAPE == PIC_TSC) wgt[s][SHAPE == PIC_TSC ? 2 : 0] = w[2];
+          xs[s] = q;
+          vs[s] = p;
+        }
+      }
+      __syncthreads();
+    }
+
+    // post-step refresh (pic.py:145-146; no external field: pic.py:114-117) from the deposit in accB
+    const double unit = ldexp(1.0, -a.fg);
+    for (int j = tid; j < Ng; j += NT) {
+      const double nj = ((double)mesh_node_sum<A, SHAPE>(accB, R, stride, Ng, a.fg, j) * unit) * a.scale;
+      io.n[row + j] = nj;
+      sb[j] = nj - a.n0;
+    }
+    __syncthreads();
+    const double gmean = scan_gradient<NW>(sb, Ng, a.dx, ws);
+    double e2 = 0.0;
+    for (int j = tid; j < Ng; j += NT) {
+      const double gp = sb[j] - gmean;
+      const double gm = sb[j == 0 ? Ng - 1 : j - 1] - gmean;
+      const double E = -0.5 * (gp + gm);
+      io.E[row + j] = E;
+      e2 += E * E;
+    }
+    const double S = block_sum<NW>(e2, ws);
+    const double K = block_sum<NW>(ke, ws);
+    if (tid == 0) {
+      const double pe = 0.5 * S * a.dx;                 // objective.py:33 / util.py:129
+      io.PEr[env] = pe;
+      io.PE[env] = pe * a.N_over_L;                     // util.py:130
+      io.KE[env] = 0.5 * K;                             // util.py:144
+      if (io.hist) {
+        double* slot = io.hist + (size_t)step * 3 * io.num_envs;
+        slot[env] = 0.5 * K;
+        slot[io.num_envs + env] = pe * a.N_over_L;
+        slot[2 * (size_t)io.num_envs + env] = pe;
+      }
+    }
+    {
+      // phi_{j+1} = phi_j + dx G_{j+1/2}: exclusive scan, then remove the mean
+      const int m = (Ng + NT - 1) / NT;
+      const int lo = min(tid * m, Ng), hi = min(lo + m, Ng);
+      double loc = 0.0, tot;
+      for (int j = lo; j < hi; ++j) loc += (sb[j] - gmean) * a.dx;
+      double run = block_excl_scan<NW>(loc, ws, tot);
+      double ploc = 0.0;
+      for (int j = lo; j < hi; ++j) {
+        se[j] = run;
+        ploc += run;
+        run += (sb[j] - gmean) * a.dx;
+      }
+      const double pmean = block_sum<NW>(ploc, ws) / (double)Ng;
+      for (int j = tid; j < Ng; j += NT) io.phi[row + j] = se[j] - pmean;
+    }
+    __syncthreads();
+  }
+
+#pragma unroll
+  for (int s = 0; s < PPT; ++s) {
+    const long long i = (long long)s * NT + tid;
+    if (i < a.N) {
+      xe[i] = xs[s];
+      ve[i] = vs[s];
+    }
+  }
+  if (bad) atomicAdd(io.bad, (unsigned long long)bad);
+}
+
+}  // namespace

@@ -6,7 +6,8 @@
 
 namespace {
 
-constexpr int SBLOCK = 256;          // field-solve workgroup: 4 waves, one workgroup per environment
+constexpr int SBLOCK = BLOCK;        // field-solve workgroup: the sweeps' size, so that every solve of the library (sweep prologue,
+                                     // resident kernel, this one) splits its scans the same way and rounds the same way
 constexpr int SWAVES = SBLOCK / 64;
 
 struct SolveIO {

@@ -66,46 +66,50 @@ __device__ __forceinline__ void push_one(typename P::X& xq, typename P::V& vp, c
   vp = p;
 }
 
-// Fold the periodic ghost slots and the replicas of one LDS mesh and add it to the environment's global
-// accumulator row with 64-bit integer atomics (executed at the memory side, order-independent; 16.8 MB per
-// sweep at config 2, hidden under the streaming of the other resident workgroups: profiles/experiments_r2.md).
+// Total of one mesh node over the R LDS replicas of a workgroup, periodic ghost slots folded in, as an integer
+// in units of 2^-fg (the unit of the global accumulators).
+template <typename A, int SHAPE>
+__device__ __forceinline__ acc_t mesh_node_sum(const A* __restrict__ acc_all, int R, int stride, int Ng, int fg, int c) {
+  constexpr int OFF = (SHAPE == PIC_TSC) ? 1 : 0;
+  if constexpr (std::is_same<A, fix_t>::value) {
+    const unsigned long long* a = reinterpret_cast<const unsigned long long*>(acc_all);
+    const int cm = c == 0 ? Ng - 1 : c - 1;
+    unsigned long long own = 0ull, left = 0ull;
+    for (int r = 0; r < R; ++r) {
+      own += a[(size_t)r * stride + c];
+      left += a[(size_t)r * stride + cm];
+    }
+    const long long mask = (1ll << FX_LOW) - 1;
+    const long long q = ((long long)(own >> FX_LOW) << FX_FRAC) - ((long long)own & mask) + ((long long)left & mask);
+    return q << (fg - FX_FRAC);                                   // 2^-24 units -> 2^-fg units
+  } else {
+    A s = A(0);
+    for (int r = 0; r < R; ++r) {
+      const A* ar = acc_all + (size_t)r * stride;
+      A t = ar[c + OFF];
+      if (SHAPE == PIC_CIC) {
+        if (c == 0) t += ar[Ng];
+      } else {
+        if (c == 0) t += ar[Ng + 1];
+        if (c == Ng - 1) t += ar[0];
+      }
+      s += t;
+    }
+    if constexpr (std::is_same<A, acc_t>::value) return s;
+    else return __double2ll_rn(ldexp((double)s, fg));
+  }
+}
+
+// Add a workgroup's LDS mesh to the environment's global accumulator row with 64-bit integer atomics (executed
+// at the memory side, order-independent; 16.8 MB per sweep at config 2, hidden under the streaming of the other
+// resident workgroups: profiles/experiments_r2.md).
 template <typename A, int SHAPE>
 __device__ __forceinline__ void flush_mesh(const A* __restrict__ acc_all, int R, int stride, int Ng, int fg,
                                            acc_t* __restrict__ row) {
-  constexpr int OFF = (SHAPE == PIC_TSC) ? 1 : 0;
   unsigned long long* out = reinterpret_cast<unsigned long long*>(row);
-  if constexpr (std::is_same<A, fix_t>::value) {
-    const unsigned long long* a = reinterpret_cast<const unsigned long long*>(acc_all);
-    for (int c = threadIdx.x; c < Ng; c += BLOCK) {
-      const int cm = c == 0 ? Ng - 1 : c - 1;
-      unsigned long long own = 0ull, left = 0ull;
-      for (int r = 0; r < R; ++r) {
-        own += a[(size_t)r * stride + c];
-        left += a[(size_t)r * stride + cm];
-      }
-      const long long mask = (1ll << FX_LOW) - 1;
-      const long long q = ((long long)(own >> FX_LOW) << FX_FRAC) - ((long long)own & mask) + ((long long)left & mask);
-      if (q) atomicAdd(out + c, (unsigned long long)(q << (fg - FX_FRAC)));          // 2^-24 units -> 2^-fg units
-    }
-  } else {
-    for (int c = threadIdx.x; c < Ng; c += BLOCK) {
-      A s = A(0);
-      for (int r = 0; r < R; ++r) {
-        const A* ar = acc_all + (size_t)r * stride;
-        A t = ar[c + OFF];
-        if (SHAPE == PIC_CIC) {
-          if (c == 0) t += ar[Ng];
-        } else {
-          if (c == 0) t += ar[Ng + 1];
-          if (c == Ng - 1) t += ar[0];
-        }
-        s += t;
-      }
-      acc_t q;
-      if constexpr (std::is_same<A, acc_t>::value) q = s;
-      else q = __double2ll_rn(ldexp((double)s, fg));
-      if (q) atomicAdd(out + c, (unsigned long long)q);
-    }
+  for (int c = threadIdx.x; c < Ng; c += BLOCK) {
+    const acc_t q = mesh_node_sum<A, SHAPE>(acc_all, R, stride, Ng, fg, c);
+    if (q) atomicAdd(out + c, (unsigned long long)q);
   }
 }
 

@@ -49,6 +49,7 @@
 #include "pic_device.h"
 #include "pic_sweep.h"
 #include "pic_solve.h"
+#include "pic_resident.h"
 #include "pic_aux.h"
 
 
@@ -71,6 +72,10 @@ struct pic_handle {
   int fg = 42;             // fractional bits of the fixed-point accumulators
   double magic = 0;
   size_t sweep_lds = 0, solve_lds = 0;
+  // resident schedule (pic_resident.h): one workgroup of res_nw waves holds an environment, res_ppt particles per lane
+  bool resident = false;
+  int res_ppt = 0, res_nw = 0, res_R = 1;
+  size_t res_lds = 0;
   double dx = 0, scale = 0;
   double cs[4]{}, ds[4]{};
   hipStream_t stream = nullptr;       // the stream every call works on (own_stream, or the caller's)
@@ -273,6 +278,54 @@ void launch_sweep(pic_handle* h, int stage, void* x, void* v, double c_prev, dou
     if (z[k] >= 0) h->clean.push_back(z[k]);      // zero for every LATER launch of this stream
 }
 
+template <typename P, typename A, int SHAPE, int PPT, int NW>
+void launch_resident_t(pic_handle* h, const ResidentIO& io, const SweepArgs& a) {
+  hipLaunchKernelGGL((resident_kernel<P, A, SHAPE, PPT, NW>), dim3(h->cfg.num_envs), dim3(NW * 64), h->res_lds, h->stream,
+                     static_cast<typename P::X*>(h->x), static_cast<typename P::V*>(h->v), io, a);
+}
+
+template <typename P, typename A, int SHAPE>
+void launch_resident_s(pic_handle* h, const ResidentIO& io, const SweepArgs& a) {
+  switch (h->res_nw * 100 + h->res_ppt) {
+    case 804: launch_resident_t<P, A, SHAPE, 4, 8>(h, io, a); break;
+    case 808: launch_resident_t<P, A, SHAPE, 8, 8>(h, io, a); break;
+    case 810: launch_resident_t<P, A, SHAPE, 10, 8>(h, io, a); break;
+    default: launch_resident_t<P, A, SHAPE, 16, 8>(h, io, a); break;
+  }
+}
+
+template <typename P>
+void launch_resident_p(pic_handle* h, const ResidentIO& io, const SweepArgs& a) {
+  const bool tsc = h->cfg.interpol == PIC_TSC;
+  if constexpr (!std::is_same<P, PosF64>::value) {
+    if (h->acc_kind == PIC_ACC_PACKED) { launch_resident_s<P, fix_t, PIC_CIC>(h, io, a); return; }
+  }
+  if (tsc) launch_resident_s<P, acc_t, PIC_TSC>(h, io, a);
+  else launch_resident_s<P, acc_t, PIC_CIC>(h, io, a);
+}
+
+// nsteps environment steps in one launch of the resident schedule; hist: device [nsteps][3][env] or null
+void launch_resident(pic_handle* h, const double* ext, int nsteps, double* hist) {
+  SweepArgs a{};
+  a.N = h->cfg.N; a.ld = h->ld; a.Ng = h->cfg.Ng; a.R = h->res_R;
+  a.fg = h->fg; a.magic = h->magic;
+  a.L = h->cfg.L; a.dx = h->dx; a.dt = h->cfg.dt;
+  a.rdx = h->fmt == FMT_F64 ? 1.0 / h->dx : (double)(1.0f / (float)h->dx);
+  a.scale = h->scale; a.n0 = h->cfg.n0;
+  a.to_units = 4294967296.0 / h->cfg.L;
+  a.N_over_L = (double)h->cfg.N / h->cfg.L;
+  ResidentIO io{};
+  io.ext = ext;
+  io.n = h->n; io.E = h->E_mesh; io.phi = h->phi; io.KE = h->KE; io.PE = h->PE; io.PEr = h->PEr;
+  io.hist = hist; io.bad = h->bad; io.nsteps = nsteps; io.num_envs = h->cfg.num_envs;
+  io.c1 = h->cs[0]; io.c2 = h->cs[1]; io.d1 = h->ds[1]; io.d2 = h->ds[2];
+  prof_begin(h, 6);
+  if (h->fmt == FMT_F64) launch_resident_p<PosF64>(h, io, a);
+  else if (h->fmt == FMT_F32) launch_resident_p<PosF32>(h, io, a);
+  else launch_resident_p<PosU32>(h, io, a);
+  prof_end(h);
+}
+
 void launch_solve(pic_handle* h, const SolveIO& io) {
   SolveArgs a;
   a.N = h->cfg.N; a.Ng = h->cfg.Ng; a.nblk = h->nblk; a.fg = h->fg; a.L = h->cfg.L; a.dx = h->dx; a.n0 = h->cfg.n0;
@@ -463,7 +516,7 @@ int pic_create(const pic_config* cfg, pic_handle** out) {
   // workgroups per environment: enough in total to fill 256 CUs several times, at least one
   // BLOCK*VEC tile each
   const long long tile = (long long)BLOCK * h->vec;
-  long long nblk = cfg->blocks_per_env;
+  long long nblk = cfg->blocks_per_env;      // workgroups per environment of the streaming sweeps (resets and probes always use them)
   if (nblk <= 0) {
     const long long target_total = 8192;      // ~128 workgroups per env at 64 envs (profiles/experiments_r1.md)
     nblk = (target_total + cfg->num_envs - 1) / cfg->num_envs;
@@ -498,6 +551,30 @@ int pic_create(const pic_config* cfg, pic_handle** out) {
   if (h->sweep_lds > 64 * 1024) {
     delete h;
     return fail(nullptr, PIC_EINVAL, "pic_create: Ng too large for the LDS-resident mesh (max 2700 cells)");
+  }
+  // Resident schedule (pic_resident.h): environments whose particles fit one workgroup's registers are stepped by
+  // one launch per pic_step call.  blocks_per_env: 0 = use it where it applies, > 0 = streaming sweeps with that many
+  // workgroups, -1 = resident or fail.
+  {
+    // 512-thread workgroups holding 4, 8, 10 or 16 particles per lane (1024 threads leave 128 registers per lane:
+    // the 10- and 16-particle bodies spill there, so larger environments stay with the sweeps)
+    static const int shapes[4][3] = {{8, 4, 2048}, {8, 8, 4096}, {8, 10, 5120}, {8, 16, 8192}};
+    for (const auto& sh : shapes)
+      if (cfg->N <= sh[2]) { h->res_nw = sh[0]; h->res_ppt = sh[1]; break; }
+    h->res_R = 4;
+    auto need = [&](int R) { return (size_t)2 * R * stride * 8 + 2 * (size_t)cfg->Ng * 8 + stride * h->esz; };
+    while (h->res_R > 1 && need(h->res_R) > 48 * 1024) h->res_R >>= 1;
+    h->res_lds = need(h->res_R);
+    const bool possible = h->res_nw != 0 && h->res_lds <= 64 * 1024 && h->acc_kind != PIC_ACC_F64;
+    if (cfg->blocks_per_env < 0 && !possible) {
+      delete h;
+      return fail(nullptr, PIC_EINVAL, "pic_create: the resident schedule needs N <= 8192, Ng <= 1600 and an integer accumulator");
+    }
+    // Measured (profiles/experiments_r2.md): one workgroup steps 5000 float64 particles in ~17 us whatever the number of
+    // environments, the sweeps need 22 us for one environment of 8000 and 35-110 us for 64-1024 of 5000.  A lone
+    // large-ish environment is therefore left to the sweeps (they spread it over many CUs).
+    const bool worth = cfg->N <= 5120 || cfg->num_envs >= 32;
+    h->resident = possible && (cfg->blocks_per_env < 0 || (cfg->blocks_per_env == 0 && worth));
   }
 
 #define CREATE_CHK(call)                                                                      \
@@ -572,6 +649,8 @@ int pic_set_stream(pic_handle* h, void* hip_stream) {
   h->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : h->own_stream;
   return PIC_OK;
 }
+
+int pic_schedule(pic_handle* h) { return h ? (h->resident ? 1 : 0) : PIC_EINVAL; }
 
 int pic_sync(pic_handle* h) {
   if (!h) return PIC_EINVAL;
@@ -683,7 +762,14 @@ int pic_step(pic_handle* h, const double* E_ext, int mem_kind, int nsteps) {
   const double* ext;
   int rc = stage_ext(h, E_ext, mem_kind, &ext);
   if (rc) return rc;
-  for (int s = 0; s < nsteps; ++s) run_stages(h, 1, 3, ext);
+  if (h->resident) {
+    if (nsteps > 0) {
+      launch_resident(h, ext, nsteps, nullptr);
+      drop_cached_deposits(h);       // the ring's q1 deposit belongs to the particles before these steps
+    }
+  } else {
+    for (int s = 0; s < nsteps; ++s) run_stages(h, 1, 3, ext);
+  }
   HIPCHK(h, hipGetLastError());
   return PIC_OK;
 }
@@ -707,11 +793,16 @@ int pic_step_history(pic_handle* h, const double* E_ext, int mem_kind, int nstep
     ext = h->ext;
     kind = PIC_DEVICE;
   }
-  for (int s = 0; s < nsteps && rc == PIC_OK; ++s) {
-    rc = pic_step(h, ext, kind, 1);
-    if (rc == PIC_OK)
-      hipLaunchKernelGGL(record_energies_kernel, dim3((E + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, h->stream, h->KE, h->PE,
-                         h->PEr, dh, s, E);
+  if (h->resident && h->has_state && !h->mid_stage) {
+    launch_resident(h, ext, nsteps, dh);        // the kernel records the energies of every step itself
+    drop_cached_deposits(h);
+  } else {
+    for (int s = 0; s < nsteps && rc == PIC_OK; ++s) {
+      rc = pic_step(h, ext, kind, 1);
+      if (rc == PIC_OK)
+        hipLaunchKernelGGL(record_energies_kernel, dim3((E + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, h->stream, h->KE, h->PE,
+                           h->PEr, dh, s, E);
+    }
   }
   hipError_t e = hipGetLastError();
   if (rc == PIC_OK && e == hipSuccess) e = hipMemcpyAsync(hist, dh, bytes, hipMemcpyDeviceToHost, h->stream);

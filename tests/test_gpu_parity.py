@@ -129,7 +129,11 @@ def test_g5_trajectory(oc, name):
     assert rel_err(sim.E_mesh, g["E_mesh_init"]) < 1e-12 and rel_err(sim.E, g["E_init"]) < 1e-12
     rew = oc.Reward(sim.init_dist.get_init_state(), int(g["Ng"]), L, -25.0, 25.0, 1.0, 1.0, 1.0)
     H, PE, KE, PEr, R = [sim.get_energy()], [sim.get_electric_energy()], [sim.get_kinetic_energy()], [], []
-    tol = {1: 1e-12, 10: 1e-11, 100: 1e-9, 500: 1e-6}
+    # (x and v, n, E_mesh) after K steps: 100 x the error measured on MI355X for the worse of the two cases (two-stream:
+    # 2.8e-16 / 4.3e-15 / 1.0e-13 at K=1 ... 8.2e-10 / 4.0e-9 / 3.8e-10 at K=500, gpurun_out/measured_r2.json; a mere
+    # particle permutation of the reference moves its own E_mesh by 1e-12 after 500 steps).  The step is
+    # bitwise reproducible, so these errors do not vary from run to run.  North star: 1e-6.
+    tol = {1: (1e-13, 5e-13, 2e-11), 10: (1e-12, 1e-11, 1e-11), 100: (1e-11, 2e-10, 5e-11), 500: (1e-7, 5e-7, 5e-8)}
     for k in range(1, 501):
         if k <= 100:
             st = sim.get_state()
@@ -138,19 +142,18 @@ def test_g5_trajectory(oc, name):
         sim.update_state(None)
         H.append(sim.get_energy()); PE.append(sim.get_electric_energy()); KE.append(sim.get_kinetic_energy())
         if k in tol:
-            t = tol[k]
+            t_xv, t_n, t_E = tol[k]
             errs = {"x": circ_err(sim.x, g[f"x_{k}"], L) / L, "v": rel_err(sim.v, g[f"v_{k}"]),
                     "E_mesh": rel_err(sim.E_mesh, g[f"E_mesh_{k}"]), "n": rel_err(sim.n, g[f"n_{k}"])}
             for q, val in errs.items():
                 record_measure(f"g5.{name}.step{k}.{q}", val)
-            assert errs["x"] < t and errs["v"] < t and errs["n"] < t, (k, errs)
-            assert errs["E_mesh"] < 100 * t, (k, errs)
+            assert errs["x"] < t_xv and errs["v"] < t_xv and errs["n"] < t_n and errs["E_mesh"] < t_E, (k, errs)
     for q, ours, ref in (("H", H, g["H"]), ("KE", KE, g["KE"]), ("PE100", PE[:101], g["PE"][:101])):
         record_measure(f"g5.{name}.trace.{q}", rel_err(ours, ref))
-    assert rel_err(H, g["H"]) < 1e-10
-    assert rel_err(KE, g["KE"]) < 1e-8
-    assert rel_err(PE[:101], g["PE"][:101]) < 1e-8
-    assert rel_err(PEr, g["PE_reward"][:100]) < 1e-8
+    assert rel_err(H, g["H"]) < 1e-10                    # measured 5.3e-13 over 500 steps
+    assert rel_err(KE, g["KE"]) < 1e-10                  # 6.8e-13
+    assert rel_err(PE[:101], g["PE"][:101]) < 1e-10      # 2.8e-13
+    assert rel_err(PEr, g["PE_reward"][:100]) < 1e-10
     assert rel_err(R, g["reward"][:100]) < 1e-10
     sim.close()
 
@@ -394,7 +397,8 @@ def test_float32_modes_track_float64(oc, po):
     _, Er, _ = ref.fields()
     xr, vr = ref.particles()
     kr, pr, _ = ref.energies()
-    bounds = {"float": dict(E=1e-4, x=5e-6, v=5e-6, pe=5e-5), "fixed32": dict(E=5e-6, x=2e-7, v=5e-6, pe=5e-6)}
+    # 3-4 x measured (float: E 1.6e-5, x 7.5e-7, v 3.7e-7, PE 3.2e-7; fixed32: E 4.2e-7, v 3.9e-7, PE 2.2e-7)
+    bounds = {"float": dict(E=5e-5, x=2.5e-6, v=1.5e-6, pe=1.5e-6), "fixed32": dict(E=1.5e-6, x=5e-8, v=1.5e-6, pe=1e-6)}
     for pos in ("float", "fixed32"):
         for acc in (None, "fixed", "fix64"):
             env = oc.BatchedPIC(1, N, Ng, L=L, dt=0.1, dtype="float32", accum_dtype=acc, position_dtype=pos)
