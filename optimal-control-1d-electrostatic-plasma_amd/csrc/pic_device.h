@@ -310,22 +310,31 @@ __device__ __forceinline__ double block_sum(double v, double* ws) {
 // ---------------------------------------------------------------------------------------------
 template <int NW>
 __device__ __forceinline__ double scan_gradient(double* __restrict__ sb, int Ng, double dx, double* __restrict__ ws) {
-  constexpr int NT = NW * 64;
+  // One wave does both scans with shuffles alone (lane l owns the m = ceil(Ng / 64) consecutive nodes from l m), the
+  // others wait at the barrier: three barriers fewer than a workgroup-wide scan, and the same rounding whatever
+  // the size of the calling workgroup (sweep prologue, resident kernel, field_solve_kernel).
   const int tid = threadIdx.x;
-  const int m = (Ng + NT - 1) / NT;
-  const int lo = min(tid * m, Ng), hi = min(lo + m, Ng);
-  double loc = 0.0;
-  for (int j = lo; j < hi; ++j) loc += sb[j];
-  double tot;
-  double run = block_excl_scan<NW>(loc, ws, tot);
-  loc = 0.0;
-  for (int j = lo; j < hi; ++j) {
-    run += sb[j];
-    const double g = run * dx;
-    sb[j] = g;
-    loc += g;
+  if (tid < 64) {
+    const int m = (Ng + 63) / 64;
+    const int lo = min(tid * m, Ng), hi = min(lo + m, Ng);
+    double loc = 0.0;
+    for (int j = lo; j < hi; ++j) loc += sb[j];
+    double run = wave_incl_scan(loc) - loc;          // exclusive prefix over the lanes
+    loc = 0.0;
+    for (int j = lo; j < hi; ++j) {
+      run += sb[j];
+      const double g = run * dx;
+      sb[j] = g;
+      loc += g;
+    }
+    double tot = loc;
+    for (int off = 32; off > 0; off >>= 1) tot += __shfl_xor(tot, off);
+    if (tid == 0) ws[0] = tot / (double)Ng;
   }
-  return block_sum<NW>(loc, ws) / (double)Ng;     // syncs: sb holds G everywhere
+  __syncthreads();                                   // sb holds G everywhere
+  const double gmean = ws[0];
+  __syncthreads();                                   // ws may be reused by the caller
+  return gmean;
 }
 
 }  // namespace

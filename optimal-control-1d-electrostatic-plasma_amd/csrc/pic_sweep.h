@@ -156,13 +156,30 @@ __global__ __launch_bounds__(BLOCK) void sweep_kernel(typename P::X* __restrict_
   const int env = a.reverse ? (int)gridDim.y - 1 - (int)blockIdx.y : (int)blockIdx.y;
   const int blk = a.reverse ? (int)gridDim.x - 1 - (int)blockIdx.x : (int)blockIdx.x;
 
+  typename P::X* xe = x + (size_t)env * a.ld;
+  typename P::V* ve = v + (size_t)env * a.ld;
+  const long long step = (long long)BLOCK * VEC;
+  // A workgroup owns one contiguous run of `chunk` particles of its environment; a lane streams 16 B of x and
+  // 16 B of v per iteration and updates them in place.  The first tile is requested before the prologue, so that
+  // its latency runs under the field solve.
+  const long long begin = (long long)blk * a.chunk;
+  long long end = begin + a.chunk;
+  if (end > a.N) end = a.N;
+  long long i = begin + (long long)tid * VEC;
+  XV xv = {};
+  VV vv = {};
+  if (i + VEC <= end) {
+    xv = *reinterpret_cast<const XV*>(xe + i);
+    if (kReadV) vv = *reinterpret_cast<const VV*>(ve + i);
+  }
+
   if (kGather)
     prologue_field<T, OFF>(io.acc_in + (size_t)env * Ng, io.ext ? io.ext + (size_t)env * Ng : nullptr, Ng,
                            ldexp(1.0, -a.fg), a.scale, a.n0, a.dx, reinterpret_cast<double*>(smem_raw), red, Es);
-  for (int i = tid; i < nacc; i += BLOCK) acc_all[i] = A{};
+  for (int c = tid; c < nacc; c += BLOCK) acc_all[c] = A{};
   if (blk == 0) {       // one workgroup per environment clears the retired accumulator rows
-    if (io.zero0) for (int i = tid; i < Ng; i += BLOCK) io.zero0[(size_t)env * Ng + i] = 0;
-    if (io.zero1) for (int i = tid; i < Ng; i += BLOCK) io.zero1[(size_t)env * Ng + i] = 0;
+    if (io.zero0) for (int c = tid; c < Ng; c += BLOCK) io.zero0[(size_t)env * Ng + c] = 0;
+    if (io.zero1) for (int c = tid; c < Ng; c += BLOCK) io.zero1[(size_t)env * Ng + c] = 0;
   }
   __syncthreads();
 
@@ -171,22 +188,9 @@ __global__ __launch_bounds__(BLOCK) void sweep_kernel(typename P::X* __restrict_
   A* acc2 = acc2_all + (size_t)rep * stride;
   const Consts<P> k(a);
 
-  typename P::X* xe = x + (size_t)env * a.ld;
-  typename P::V* ve = v + (size_t)env * a.ld;
-  const long long step = (long long)BLOCK * VEC;
-
   double ke = 0.0;
   unsigned bad = 0u;
-  // A workgroup owns one contiguous run of `chunk` particles of its environment; a lane streams 16 B of x and
-  // 16 B of v per iteration and updates them in place.
-  const long long begin = (long long)blk * a.chunk;
-  long long end = begin + a.chunk;
-  if (end > a.N) end = a.N;
-  long long i = begin + (long long)tid * VEC;
-  for (; i + VEC <= end; i += step) {
-    XV xv = *reinterpret_cast<const XV*>(xe + i);
-    VV vv = {};
-    if (kReadV) vv = *reinterpret_cast<const VV*>(ve + i);
+  while (i + VEC <= end) {
     typename P::X* xs = reinterpret_cast<typename P::X*>(&xv);
     typename P::V* vs = reinterpret_cast<typename P::V*>(&vv);
 #pragma unroll
@@ -198,6 +202,11 @@ __global__ __launch_bounds__(BLOCK) void sweep_kernel(typename P::X* __restrict_
     if (kStore) {
       *reinterpret_cast<XV*>(xe + i) = xv;
       if (kStoreV) *reinterpret_cast<VV*>(ve + i) = vv;
+    }
+    i += step;
+    if (i + VEC <= end) {
+      xv = *reinterpret_cast<const XV*>(xe + i);
+      if (kReadV) vv = *reinterpret_cast<const VV*>(ve + i);
     }
   }
   for (long long c = i; c < end; ++c) {       // ragged tail (fewer than VEC particles left for this lane)
