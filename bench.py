@@ -237,6 +237,8 @@ def main():
         esz = 8 if args.dtype == "float64" else 4
         for k, (ms, cnt) in prof.items():
             kernels[k] = {"avg_ms": ms / cnt, "launches": cnt}
+            if k == "resident":
+                kernels[k]["steps_per_launch"] = psteps
         if "resident" in prof:
             # small environments: the whole call is one launch that reads and writes the particles once and keeps
             # them in registers in between; the step is bound by latency and VALU issue, not by HBM

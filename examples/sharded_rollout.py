@@ -53,19 +53,23 @@ def main():
     env = sh.env                                           # this rank's BatchedPIC: environments [sh.lo, sh.hi)
     env.set_actuator(E_field(L, args.mesh, args.modes))
     env.reset_sampled("two-stream", v0=3.0, sigma=1.0, A=0.1, n_mode=2, seed=1000)   # keyed by the global env index
-    returns = np.zeros(sh.num_local)
+    # The control loop stays on the device and on one stream: modes -> action (torch) -> actuator + step -> reward view.
+    env.use_torch_stream()
+    returns = torch.zeros(sh.num_local, dtype=torch.float64, device=f"cuda:{device}")
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        returns += env.rewards()                           # reward of the pre-step state (ddpg.py:455)
-        env.step_actions(args.gain * env.feedback_actions(args.modes))
-    env.sync()
+        returns += env.rewards_torch()                     # reward of the pre-step state (ddpg.py:455)
+        env.step_actions_torch(args.gain * env.feedback_actions_torch(args.modes))
+    torch.cuda.current_stream().synchronize()
     elapsed = time.perf_counter() - t0
-    all_returns = sh.gather(returns)                       # the one collective: [envs] on every rank
+    # the one collective: [envs] on every rank, on the collective's device (RCCL: no host hop)
+    all_returns = sh.gather_tensor(returns).cpu().numpy()
+    env.use_own_stream()
     all_energy = sh.gather_energies()
     if rank == 0:
         rate = args.envs * args.particles * args.steps / elapsed
         print(f"{world} rank(s) x {sh.num_local} envs: {args.steps} controlled steps in {elapsed:.3f} s "
-              f"({rate:.3e} particle-steps/s incl. the per-step feedback round trip)")
+              f"({rate:.3e} particle-steps/s incl. the per-step feedback law, no host synchronisation in the loop)")
         print("episode returns:", np.array2string(all_returns, precision=3, max_line_width=120))
         print(f"final field energy per env: min {all_energy[:, 2].min():.3e} max {all_energy[:, 2].max():.3e}")
         if args.out:

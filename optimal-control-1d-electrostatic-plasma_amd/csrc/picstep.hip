@@ -520,10 +520,10 @@ int pic_create(const pic_config* cfg, pic_handle** out) {
   if (nblk <= 0) {
     const long long target_total = 8192;      // ~128 workgroups per env at 64 envs (profiles/experiments_r1.md)
     nblk = (target_total + cfg->num_envs - 1) / cfg->num_envs;
-    // Large problems: >= 8 tiles per workgroup (amortises the prologue and the flush).  Small, launch-bound
-    // problems (profiles/smalln_bpe.py: N = 1e4 41 -> 30 us/step, N = 5e3 36 -> 28 us/step): one tile per
-    // workgroup, at most 64 workgroups per environment.
-    const bool small = (double)cfg->N * cfg->num_envs <= 4.0e6;
+    // Large environments: >= 8 tiles per workgroup (amortises the prologue and the flush).  Small ones in small
+    // ensembles are latency-bound (profiles/experiments_r2.md: N = 1e5 13 -> 98 workgroups 47 -> 28 us/step; N = 1e6
+    // is best at 122 whatever the number of environments): one tile per workgroup, at most 64 workgroups per environment.
+    const bool small = (double)cfg->N * cfg->num_envs <= 4.0e6 && cfg->N <= 131072;
     const long long tiles_min = small ? 1 : 8;
     long long max_by_work = (cfg->N + tiles_min * tile - 1) / (tiles_min * tile);
     if (small && max_by_work > 64) max_by_work = 64;

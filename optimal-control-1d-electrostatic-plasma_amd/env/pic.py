@@ -108,6 +108,24 @@ class PIC:
         self._ensure_handle().reset(x, v)
         self._invalidate()
 
+    # Dense mesh operators of the reference object (pic.py:52-53).  The device path has no use for them (its field
+    # solve is two scans); they are built on first access for callers that read the attributes.
+    @property
+    def grad(self):
+        from .util import generate_grad
+        key = ("grad", float(self.L), self.N_mesh)
+        if getattr(self, "_grad_key", None) != key:
+            self._grad, self._grad_key = generate_grad(self.L, self.N_mesh), key
+        return self._grad
+
+    @property
+    def laplacian(self):
+        from .util import generate_laplacian
+        key = ("lap", float(self.L), self.N_mesh)
+        if getattr(self, "_lap_key", None) != key:
+            self._lap, self._lap_key = generate_laplacian(self.L, self.N_mesh), key
+        return self._lap
+
     @property
     def n(self):
         return self._fields()["n"]

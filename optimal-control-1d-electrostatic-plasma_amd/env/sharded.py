@@ -63,6 +63,50 @@ class ShardedPIC:
             E_external = self.local_slice(E_external)
         self.env.step(E_external, nsteps)
 
+    # -- tensor path: the exchange stays on the collective's device (RCCL: the GPU; gloo: the host) ----------------
+    def broadcast_actions_tensor(self, actions=None, src: int = 0, width: Optional[int] = None, dtype=None):
+        """[total_envs, A] actions decided on rank `src` -> this rank's rows [num_local, A], as a tensor on the
+        collective's device and without a NumPy hop.  Ranks other than `src` may pass None together with `width`
+        (= A).  With RCCL the result is a CUDA tensor that `env.step_actions_torch` consumes in stream order."""
+        import torch
+        dev = self._backend_device()
+        dtype = dtype or torch.float64
+        if actions is not None:
+            t = torch.as_tensor(actions, dtype=dtype).to(dev).contiguous()
+        else:
+            if width is None:
+                raise ValueError("a rank that passes no actions must pass `width`")
+            t = torch.empty((self.total_envs, int(width)), dtype=dtype, device=dev)
+        if self.world > 1:
+            self.dist.broadcast(t, src=src)
+        return t[self.lo:self.hi].contiguous()
+
+    def gather_tensor(self, local):
+        """All-gather of a per-environment tensor [num_local, ...] -> [total_envs, ...] in global environment order,
+        identical on every rank, on the collective's device (ragged shards are padded to the largest one)."""
+        import torch
+        dev = self._backend_device()
+        loc = local.to(dev)
+        if self.world == 1:
+            return loc
+        tail = tuple(loc.shape[1:])
+        pad = max(hi - lo for lo, hi in self.counts)
+        buf = torch.zeros((pad,) + tail, dtype=loc.dtype, device=dev)
+        buf[: self.num_local] = loc
+        out = [torch.empty_like(buf) for _ in range(self.world)]
+        self.dist.all_gather(out, buf)
+        return torch.cat([o[: hi - lo] for o, (lo, hi) in zip(out, self.counts)], dim=0)
+
+    def gather_returns_tensor(self):
+        """max(1 - PE_r, 0) of every environment of every rank (reward.py:72); with RCCL neither the reward nor the
+        gathered result leaves the device."""
+        import torch
+        if hasattr(self.env, "rewards_torch") and self._backend_device().type == "cuda":
+            self.env.sync()
+            return self.gather_tensor(self.env.rewards_torch())
+        return self.gather_tensor(torch.as_tensor(np.ascontiguousarray(self.env.rewards(), dtype=np.float64)))
+
+    # -- NumPy path (thin wrappers over the tensor path) -----------------------------------------------------------
     def broadcast_actions(self, actions, src: int = 0):
         """[total_envs, A] actions decided on `src` -> every rank (then `local_slice`)."""
         import torch
@@ -78,14 +122,7 @@ class ShardedPIC:
         loc = np.ascontiguousarray(local_values, dtype=np.float64)
         if self.world == 1:
             return loc
-        dev = self._backend_device()
-        tail = loc.shape[1:]
-        pad = max(hi - lo for lo, hi in self.counts)
-        buf = torch.zeros((pad,) + tail, dtype=torch.float64, device=dev)
-        buf[: self.num_local] = torch.as_tensor(loc, device=dev)
-        out = [torch.empty_like(buf) for _ in range(self.world)]
-        self.dist.all_gather(out, buf)
-        return np.concatenate([o[: hi - lo].cpu().numpy() for o, (lo, hi) in zip(out, self.counts)], axis=0)
+        return self.gather_tensor(torch.as_tensor(loc)).cpu().numpy()
 
     def gather_returns(self):
         """Per-environment reward of the current state, max(1 - PE_r, 0) (reward.py:72), for all ranks."""

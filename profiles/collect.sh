@@ -1,24 +1,43 @@
 #!/bin/bash
 # Collect the judged artifact set on the GPU box (one gpurun call):
-#   bash profiles/collect.sh r1
-# writes gpurun_out/<tag>_* ; copy the summaries into profiles/ afterwards (the kernel trace is trimmed by summarize.py).
+#   bash profiles/collect.sh r2
+# writes gpurun_out/<tag>_* and profiles/<tag>_{kernel_stats.csv,summary.json,summary.md}; the other files are copied
+# into profiles/ by hand afterwards (the raw kernel trace is large).
 set -o pipefail
-TAG=${1:-r1}
+TAG=${1:-r2}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-# 1. unprofiled bench line (with the CPU baseline leg)
+# 1. unprofiled bench line (with the 1-core CPU baseline leg)
 python3 $ROOT/bench.py --steps 20 --warmup 3 > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err || exit 1
+echo "bench done"
 # 2. kernel trace + stats of the same command (its own JSON line is kept: the profiled process runs slower)
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_kt -o kt -- python3 $ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline \
   > $OUT/${TAG}_bench_under_rocprofv3.json 2> $OUT/${TAG}_kt.err || exit 1
+echo "kernel trace done"
 # 3. HBM traffic: one counter per pass, nothing else enabled
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/${TAG}_pmc_fetch -o pf -- python3 $ROOT/bench.py --steps 5 --warmup 1 --no-cpu-baseline \
   > /dev/null 2> $OUT/${TAG}_pf.err || exit 1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/${TAG}_pmc_write -o pw -- python3 $ROOT/bench.py --steps 5 --warmup 1 --no-cpu-baseline \
   > /dev/null 2> $OUT/${TAG}_pw.err || exit 1
+echo "pmc passes done"
 cd $ROOT && python3 profiles/summarize.py $TAG $OUT/${TAG}_kt $OUT/${TAG}_pmc_fetch $OUT/${TAG}_pmc_write
 cp "$(ls $OUT/${TAG}_kt/*/*_kernel_trace.csv $OUT/${TAG}_kt/*_kernel_trace.csv 2>/dev/null | head -1)" $OUT/${TAG}_kernel_trace.csv
+# 4. the other regimes under the same profiler: Infinity-Cache resident (12 envs) and the reference's small environments
+cd /tmp
+SUMMARY_WORKLOAD="bench.py --envs 12 (N=1e6, Ng=256, fp64: particles resident in the 256 MB Infinity Cache)" \
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_kt_env12 -o kt -- python3 $ROOT/bench.py --steps 100 --warmup 10 --envs 12 --no-cpu-baseline \
+  > $OUT/${TAG}_env12_under_rocprofv3.json 2> $OUT/${TAG}_kt_env12.err || exit 1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_kt_small -o kt -- python3 $ROOT/bench.py --steps 200 --warmup 20 --envs 256 --particles 5000 --mesh 250 --no-cpu-baseline \
+  > $OUT/${TAG}_small256_under_rocprofv3.json 2> $OUT/${TAG}_kt_small.err || exit 1
+for d in env12 small; do cp "$(ls $OUT/${TAG}_kt_$d/*/*_kernel_stats.csv $OUT/${TAG}_kt_$d/*_kernel_stats.csv 2>/dev/null | head -1)" $OUT/${TAG}_kernel_stats_$d.csv; done
+echo "regime traces done"
+cd $ROOT
 cp profiles/${TAG}_kernel_stats.csv profiles/${TAG}_summary.json profiles/${TAG}_summary.md $OUT/ 2>/dev/null
-ls -la $OUT | tail -20
+# 5. the regime table: unprofiled bench lines (HIP-event kernel times) at every BASELINE configuration share and regime
+python3 profiles/regimes.py $OUT/${TAG}_regimes > $OUT/${TAG}_regimes.md 2> $OUT/${TAG}_regimes.err
+# 6. CPU comparators of SURVEY 8d: (a) one core at config 1, (b) one process per core at config 2
+python3 bench.py --steps 200 --warmup 20 --envs 1 --particles 10000 --mesh 128 > $OUT/${TAG}_bench_config1.json 2> /dev/null
+python3 bench.py --steps 20 --warmup 3 --cpu-procs 16 > $OUT/${TAG}_bench_cpu16.json 2> /dev/null
+ls -la $OUT | tail -30

@@ -19,6 +19,8 @@ def short(name):
     if "sweep_kernel<" in name:
         args = [a.strip() for a in name.split("sweep_kernel<")[1].split(">")[0].split(",")]
         return STAGES.get(args[3], "sweep_" + args[3])
+    if "resident_kernel<" in name:
+        return "resident"
     if "field_solve_kernel" in name:
         return "field_solve"
     if "stream_probe" in name:
@@ -64,7 +66,7 @@ def main():
             d["hbm_bytes_per_launch"] = d["hbm_read_bytes_per_launch"] + d["hbm_write_bytes_per_launch"]
     json.dump(out, open(os.path.join(here, f"{tag}_summary.json"), "w"), indent=1)
     with open(os.path.join(here, f"{tag}_summary.md"), "w") as f:
-        f.write(f"# rocprofv3 summary `{tag}`\n\nbench.py config 2 (N=1e6, Ng=256, 64 envs, fp64). Durations: "
+        f.write(f"# rocprofv3 summary `{tag}`\n\n{os.environ.get('SUMMARY_WORKLOAD', 'bench.py config 2 (N=1e6, Ng=256, 64 envs, fp64)')}. Durations: "
                 "`--kernel-trace --stats`; HBM bytes: separate `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes, "
                 "FETCH_SIZE x2 (gfx950 wide-read correction), KiB -> bytes.\n\n"
                 "| kernel | calls | avg us | min us | max us | HBM read MB | HBM write MB | HBM total MB |\n|---|---|---|---|---|---|---|---|\n")

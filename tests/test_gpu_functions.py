@@ -10,6 +10,12 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.fixture(scope="module")
+def oc():
+    import ocplasma_amd
+    return ocplasma_amd
+
+
+@pytest.fixture(scope="module")
 def mods():
     import ocplasma_amd  # noqa: F401
     from ocplasma_amd.env import interpolate, solve, util
@@ -106,3 +112,83 @@ def test_periodic_solver_function(mods):
         solve.Gaussian_Elimination_Periodic(np.eye(16), np.zeros(16))                 # not a Laplacian
     with pytest.raises(ValueError):
         solve.Gaussian_Elimination_Periodic(util.generate_laplacian(L, 16), np.zeros(15))
+
+
+def test_cfl_clamp_table_through_the_drop_in_classes(oc):
+    """golden g7: PIC.initialize's CFL clamp dt = min(dt, 2 / sqrt(N / L)) (pic.py:71-73) as the reference applied it,
+    through PIC and BatchedPIC (the oracle is checked against the same table in tests/test_oracle_golden.py)."""
+    from conftest import load_golden
+
+    class Uniform:
+        def __init__(self, N, L):
+            self.N, self.L = N, L
+
+        def reinit(self):
+            pass
+
+        def get_sample(self):
+            rng = np.random.default_rng(self.N)
+            return rng.uniform(0, self.L, self.N), rng.normal(0, 1, self.N)
+
+    for N, L, dt_in, dt_ref in load_golden("g7_cfl")["table"]:
+        N = int(N)
+        sim = oc.PIC(N=N, N_mesh=64, L=float(L), dt=float(dt_in), init_dist=Uniform(N, float(L)))
+        assert sim.dt == dt_ref
+        sim.update_state(None)                       # the handle really steps with the clamped dt
+        assert sim._ensure_handle().cfg.dt == dt_ref
+        sim.close()
+        env = oc.BatchedPIC(2, N, 64, L=float(L), dt=float(dt_in))
+        assert env.dt == dt_ref and env._h.cfg.dt == dt_ref
+        env.close()
+
+
+def test_dense_operator_attributes_of_the_drop_in(oc):
+    """PIC.grad / PIC.laplacian (pic.py:52-53): the reference object's dense operators, for callers that read them."""
+    from oracle import pic_oracle as po
+
+    class D:
+        def reinit(self):
+            pass
+
+        def get_sample(self):
+            return np.linspace(0, 49, 500), np.zeros(500)
+
+    sim = oc.PIC(N=500, N_mesh=32, L=50.0, dt=0.1, init_dist=D())
+    assert np.array_equal(sim.grad, po.dense_grad(50.0, 32)) and np.array_equal(sim.laplacian, po.dense_laplacian(50.0, 32))
+    assert sim.grad is sim.grad                     # built once
+    # E_mesh = -grad @ phi_mesh, laplacian @ phi_mesh = n - n0 hold for the device fields (zero-mean gauge)
+    sim.update_state(None)
+    assert rel_err(-sim.grad @ sim.phi_mesh, sim.E_mesh) < 1e-10
+    assert np.max(np.abs(sim.laplacian @ sim.phi_mesh - (sim.n.reshape(-1, 1) - sim.n0))) < 1e-9
+    sim.close()
+
+
+def test_integration_md_ctypes_stub_runs_verbatim(oc):
+    """the reference-side ctypes binding a maintainer would add, executed as printed (only
+    the library name is made absolute) and checked against the reference's own one-step output (golden g4)."""
+    import os
+    import re
+    from conftest import ROOT, circ_err, load_golden
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    sec = text[text.index("## B."):text.index("## C.")]
+    code = re.search(r"```python\n(.*?)```", sec, re.S).group(1)
+    assert "class HipStepper" in code and "pic_create" in code
+    code = code.replace('C.CDLL("libpicstep.so")', f'C.CDLL({oc._abi.library_path()!r})')
+    ns = {}
+    exec(compile(code, "INTEGRATION.md#B", "exec"), ns)
+    g = load_golden("g4_bump_on_tail_ext_N4000_Ng256")
+
+    class RefPIC:                                     # the attributes the stub reads off the reference object
+        N, N_mesh, L, n0, dt, gamma, interpol = int(g["N"]), int(g["Ng"]), float(g["L"]), float(g["n0"]), float(g["dt"]), float(g["gamma"]), "CIC"
+
+    st = ns["HipStepper"](RefPIC)
+    st.reset(g["x_init"][:, 0], g["v_init"][:, 0])
+    act = oc.E_field(RefPIC.L, RefPIC.N_mesh, 3)
+    a = g["actions"][0]
+    act.update_E(a[:3], a[3:])
+    st.update_state(act.compute_E()[:, 0])
+    x, v, n, E, phi = st.fetch()
+    assert circ_err(x, g["x_1"], RefPIC.L) / RefPIC.L < 1e-13 and rel_err(v, g["v_1"]) < 1e-13
+    assert rel_err(n, g["n_1"]) < 1e-12 and rel_err(E, g["E_mesh_1"]) < 1e-11
+    H, PE, PEr = st.energies()
+    assert abs(H / float(g["H"][1]) - 1) < 1e-12

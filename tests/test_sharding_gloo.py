@@ -67,10 +67,17 @@ def _worker(rank, world, port, out):
     act = E_field(L, NG, 2)
     rng = np.random.default_rng(7)          # only rank 0's draw matters: it is broadcast
     actions = rng.uniform(-1, 1, (TOTAL, 4)) if rank == 0 else np.zeros((TOTAL, 4))
+    drawn = actions
     actions = env.broadcast_actions(actions, src=0)
+    # the tensor path: rank 0 hands over its tensor, the others only say how wide it is; everybody gets its own rows
+    mine = env.broadcast_actions_tensor(torch.as_tensor(drawn) if rank == 0 else None, src=0, width=4)
+    assert isinstance(mine, torch.Tensor) and tuple(mine.shape) == (env.num_local, 4)
+    assert np.array_equal(mine.numpy(), actions[env.lo:env.hi])
     env.step(act.compute_E_batched(actions), nsteps=2, is_global=True)
+    ke, pe, per = env.env.energies()
+    gathered = env.gather_tensor(torch.as_tensor(np.stack([ke, pe, per], axis=1)))      # ragged: 3 + 2 rows
     res = {"range": (env.lo, env.hi), "returns": env.gather_returns(), "energies": env.gather_energies(),
-           "actions": actions}
+           "actions": actions, "returns_tensor": env.gather_returns_tensor().numpy(), "energies_tensor": gathered.numpy()}
     out[rank] = res
     dist.destroy_process_group()
 
@@ -101,8 +108,10 @@ def test_two_rank_sharded_rollout_matches_single_process():
     mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
     assert out[0]["range"] == (0, 3) and out[1]["range"] == (3, 5)
     # every rank holds the same gathered arrays, in global env order
-    for k in ("returns", "energies", "actions"):
+    for k in ("returns", "energies", "actions", "returns_tensor", "energies_tensor"):
         assert np.array_equal(out[0][k], out[1][k]), k
+    assert np.array_equal(out[0]["returns_tensor"], out[0]["returns"])            # tensor path == NumPy path
+    assert np.array_equal(out[0]["energies_tensor"], out[0]["energies"]) and out[0]["energies_tensor"].shape == (TOTAL, 3)
     # and they equal an unsharded run
     x0, v0 = _inputs()
     ref = OracleBatch(TOTAL, N, NG, L=L, dt=0.1)
