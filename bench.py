@@ -101,7 +101,7 @@ def cpu_baseline(N, Ng, L, dt, budget_s=20.0, procs=1):
         steps, el = _cpu_env((N, Ng, L, dt, budget_s, 1234))
         return {"value": N * steps / el, "unit": "particle-steps/s", "cores": 1, "kind": "port",
                 "sample": f"1 env of N={N}, Ng={Ng}, {steps} steps of the NumPy oracle (faithful call structure), "
-                          f"{el / steps * 1e3:.0f} ms/step", "host": _host_cpu()}
+                          f"{el / steps * 1e3:.3g} ms/step", "host": _host_cpu()}
     import multiprocessing as mp
     with mp.get_context("spawn").Pool(procs) as pool:
         t0 = time.perf_counter()

@@ -80,8 +80,8 @@ SIGNATURES = {
 
 
 def library_path():
-    # PICSTEP_LIB selects a timing-experiment build (see _build.build_variant); default is the product
-    return os.environ.get("PICSTEP_LIB") or _build.LIB
+    """The one library this package loads: csrc/libpicstep.so next to it (no environment override)."""
+    return _build.LIB
 
 
 def _preload_torch_hip_runtime():

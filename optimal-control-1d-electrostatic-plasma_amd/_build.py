@@ -48,11 +48,3 @@ def build_library(force=False, verbose=False):
     if not force and not needs_build():
         return LIB
     return _compile(LIB, (), verbose)
-
-
-def build_variant(name, defines, verbose=False):
-    """Timing-experiment builds (csrc/exp/libpicstep_<name>.so, selected with PICSTEP_LIB): they
-    change results and are never loaded by default."""
-    d = os.path.join(HERE, "csrc", "exp")
-    os.makedirs(d, exist_ok=True)
-    return _compile(os.path.join(d, f"libpicstep_{name}.so"), defines, verbose)
