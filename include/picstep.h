@@ -207,11 +207,13 @@ int pic_profile_read(pic_handle* h, double* ms_sum, int64_t* launches);
  * scratch arrays of the handle's particle footprint.  bench.py reports it next to the 8 TB/s spec. */
 int pic_stream_probe(pic_handle* h, int repeats, double* gbytes_per_s);
 
-/* Run all further work of this handle on the caller's HIP stream (a hipStream_t, e.g. torch's current
- * stream) instead of the handle's own; NULL switches back.  The previous stream is drained first.  With
- * device-pointer inputs/outputs (pic_step, pic_step_actions, pic_get_modes, pic_device_ptrs views) a
- * control loop then stays stream-ordered with the caller's kernels and needs no host synchronisation. */
+/* Run all further work of this handle on the caller's HIP stream (a hipStream_t, e.g. torch's current stream; NULL
+ * is the device's default stream, which is what torch uses unless told otherwise) instead of the handle's own;
+ * pic_own_stream switches back.  The previous stream is drained first.  With device-pointer inputs/outputs (pic_step,
+ * pic_step_actions, pic_get_modes, pic_device_ptrs views) a control loop then stays stream-ordered with the caller's
+ * kernels and needs no host synchronisation. */
 int pic_set_stream(pic_handle* h, void* hip_stream);
+int pic_own_stream(pic_handle* h);
 
 /* 1 if pic_step runs the resident schedule on this handle, 0 for streaming sweeps (see blocks_per_env). */
 int pic_schedule(pic_handle* h);

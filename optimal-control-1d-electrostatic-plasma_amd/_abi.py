@@ -71,6 +71,7 @@ SIGNATURES = {
     "pic_phase_histogram": [_vp, C.c_int, C.c_double, C.c_double, _vp],
     "pic_stream_probe": [_vp, C.c_int, _dp],
     "pic_set_stream": [_vp, _vp],
+    "pic_own_stream": [_vp],
     "pic_schedule": [_vp],
     "pic_sync": [_vp],
     "pic_bad_count": [_vp, _i64p],
@@ -341,8 +342,11 @@ class Handle:
         self._chk(self.lib.pic_step_actions(self._h, _ptr(int(actions_ptr)), PIC_DEVICE, int(nsteps)))
 
     def set_stream(self, hip_stream):
-        """hip_stream: integer hipStream_t (e.g. torch.cuda.current_stream().cuda_stream), or 0/None."""
+        """hip_stream: integer hipStream_t (e.g. torch.cuda.current_stream().cuda_stream; 0 = the default stream)."""
         self._chk(self.lib.pic_set_stream(self._h, C.c_void_p(int(hip_stream)) if hip_stream else None))
+
+    def own_stream(self):
+        self._chk(self.lib.pic_own_stream(self._h))
 
     def modes_device(self, max_mode, re_ptr, im_ptr):
         self._chk(self.lib.pic_get_modes(self._h, int(max_mode), _ptr(int(re_ptr)), _ptr(int(im_ptr)), PIC_DEVICE))

@@ -111,6 +111,7 @@ struct pic_handle {
   double* PE = nullptr;
   double* PEr = nullptr;
   double* h_scal = nullptr;       // pinned host staging for KE | PE | PE_reward
+  void* h_part = nullptr;         // pinned host staging for x | v of small states (null for large ones)
   unsigned long long* bad = nullptr;
   bool has_state = false;
   // profiling
@@ -592,10 +593,13 @@ int pic_create(const pic_config* cfg, pic_handle** out) {
   h->stream = h->own_stream;
   const size_t pbytes = (size_t)cfg->num_envs * h->ld * h->esz;
   const size_t gbytes = (size_t)cfg->num_envs * cfg->Ng * sizeof(double);
-  CREATE_CHK(hipMalloc(&h->x, pbytes));
-  CREATE_CHK(hipMalloc(&h->v, pbytes));
-  CREATE_CHK(hipMemsetAsync(h->x, 0, pbytes, h->stream));
-  CREATE_CHK(hipMemsetAsync(h->v, 0, pbytes, h->stream));
+  CREATE_CHK(hipMalloc(&h->x, 2 * pbytes));          // x and v in one allocation: [2][env][ld]
+  h->v = static_cast<char*>(h->x) + pbytes;
+  CREATE_CHK(hipMemsetAsync(h->x, 0, 2 * pbytes, h->stream));
+  // small states (the reference's N = 5000) are read back every step by a Gym-style loop: one copy of x and v
+  // together into pinned memory instead of two copies into pageable memory
+  if (2 * (size_t)cfg->num_envs * cfg->N * h->esz <= ((size_t)4 << 20))
+    CREATE_CHK(hipHostMalloc(&h->h_part, 2 * (size_t)cfg->num_envs * cfg->N * h->esz, hipHostMallocDefault));
   CREATE_CHK(hipMalloc((void**)&h->ring, (size_t)(RING + 1) * gbytes));      // acc_t and double are both 8 bytes
   CREATE_CHK(hipMemsetAsync(h->ring, 0, (size_t)(RING + 1) * gbytes, h->stream));
   h->probe_acc = h->ring + (size_t)RING * cfg->num_envs * cfg->Ng;
@@ -631,23 +635,33 @@ int pic_destroy(pic_handle* h) {
   if (h->stream) hipStreamSynchronize(h->stream);
   prof_drain(h);
   for (hipEvent_t e : h->ev) hipEventDestroy(e);
-  void* bufs[] = {h->x, h->v, h->scratch, h->stage, h->ring, h->ke_part, h->n, h->E_mesh, h->phi, h->ext, h->probe_ext,
+  void* bufs[] = {h->x, h->scratch, h->stage, h->ring, h->ke_part, h->n, h->E_mesh, h->phi, h->ext, h->probe_ext,
                   h->basis, h->act, h->modes, h->aux_n, h->aux_E, h->aux_pe, h->aux_phi, h->KE, h->bad};
   for (void* b : bufs)
     if (b) hipFree(b);
   if (h->h_scal) hipHostFree(h->h_scal);
+  if (h->h_part) hipHostFree(h->h_part);
   if (h->own_stream) hipStreamDestroy(h->own_stream);
   delete h;
   return PIC_OK;
 }
 
-int pic_set_stream(pic_handle* h, void* hip_stream) {
-  if (!h) return PIC_EINVAL;
+static int switch_stream(pic_handle* h, hipStream_t next) {
   HIPCHK(h, hipSetDevice(h->cfg.device_id));
   HIPCHK(h, hipStreamSynchronize(h->stream));      // drain the old stream: later work must see its results
   prof_drain(h);
-  h->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : h->own_stream;
+  h->stream = next;
   return PIC_OK;
+}
+
+int pic_set_stream(pic_handle* h, void* hip_stream) {
+  if (!h) return PIC_EINVAL;
+  return switch_stream(h, static_cast<hipStream_t>(hip_stream));      // NULL is a stream too: the device's default stream
+}
+
+int pic_own_stream(pic_handle* h) {
+  if (!h) return PIC_EINVAL;
+  return switch_stream(h, h->own_stream);
 }
 
 int pic_schedule(pic_handle* h) { return h ? (h->resident ? 1 : 0) : PIC_EINVAL; }
@@ -817,6 +831,16 @@ int pic_step_history(pic_handle* h, const double* E_ext, int mem_kind, int nstep
 int pic_get_particles(pic_handle* h, void* x, void* v, int mem_kind) {
   if (!h) return PIC_EINVAL;
   HIPCHK(h, hipSetDevice(h->cfg.device_id));
+  if (x && v && mem_kind == PIC_HOST && h->h_part && h->fmt != FMT_U32) {
+    // x and v are adjacent on the device: one strided copy of both into pinned memory
+    const size_t row = (size_t)h->cfg.N * h->esz, half = row * h->cfg.num_envs;
+    HIPCHK(h, hipMemcpy2DAsync(h->h_part, row, h->x, (size_t)h->ld * h->esz, row, 2 * (size_t)h->cfg.num_envs,
+                               hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    std::memcpy(x, h->h_part, half);
+    std::memcpy(v, static_cast<char*>(h->h_part) + half, half);
+    return PIC_OK;
+  }
   int rc = PIC_OK;
   if (x) rc = download_positions(h, x, h->x, mem_kind);
   if (!rc && v) rc = download(h, v, h->v, mem_kind);

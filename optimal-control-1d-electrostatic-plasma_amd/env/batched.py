@@ -133,7 +133,7 @@ class BatchedPIC:
         self._torch_stream = st
 
     def use_own_stream(self):
-        self._h.set_stream(None)
+        self._h.own_stream()
         self._torch_stream = None
 
     def step_actions_torch(self, actions, nsteps: int = 1):

@@ -73,8 +73,8 @@ class PIC:
     def _particles(self):
         if "x" not in self._cache:
             x, v = self._ensure_handle().particles()
-            self._cache["x"] = x.astype(np.float64).reshape(-1, 1)
-            self._cache["v"] = v.astype(np.float64).reshape(-1, 1)
+            self._cache["x"] = np.asarray(x, dtype=np.float64).reshape(-1, 1)
+            self._cache["v"] = np.asarray(v, dtype=np.float64).reshape(-1, 1)
         return self._cache["x"], self._cache["v"]
 
     def _fields(self):
@@ -246,7 +246,7 @@ class PIC:
 
     def get_state(self):
         x, v = self._particles()
-        return np.concatenate([x.copy().reshape(-1, 1), v.copy().reshape(-1, 1)], axis=0)
+        return np.concatenate([x, v], axis=0)             # a fresh (2N, 1) array, as the reference returns
 
     def _energies(self):
         """(KE, PE, PE_reward) of the current state: one small device read per step, then cached."""

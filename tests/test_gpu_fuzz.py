@@ -35,14 +35,17 @@ def test_random_shapes_against_oracle():
         x0 = rng.uniform(-0.25 * L, 1.25 * L, (envs, N))          # includes positions outside the box
         v0 = rng.normal(0.0, 1.0, (envs, N)) * rng.choice([0.1, 1.0, 3.0])
         E_ext = rng.uniform(-0.5, 0.5, (envs, Ng)) if ext else None
-        env = oc.BatchedPIC(envs, N, Ng, n0=n0, L=L, dt=dt, interpol=interpol)
+        # alternate between the two schedules: resident (one workgroup per environment) and streaming sweeps with a
+        # random number of workgroups per environment
+        bpe = 0 if rng.integers(0, 2) else int(rng.integers(1, 6))
+        env = oc.BatchedPIC(envs, N, Ng, n0=n0, L=L, dt=dt, interpol=interpol, blocks_per_env=bpe)
         env.reset(x0, v0)
         env.step(E_ext, nsteps=2)
         x, v = env.particles()
         n, Em, phi = env.fields()
         ke, pe, per = env.energies()
         assert env.bad_count() == 0
-        tag = (N, Ng, L, n0, dt, interpol, envs, ext)
+        tag = (N, Ng, L, n0, dt, interpol, envs, ext, bpe, env._h.schedule())
         for e in range(envs):
             try:
                 with np.errstate(all="ignore"):

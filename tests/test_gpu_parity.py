@@ -672,9 +672,12 @@ def test_feedback_control_loop_on_device():
     assert effort.max() < 1.25                         # inside the trainers' action range (|a| <= 1.25)
 
 
-def test_stream_ordered_torch_loop_matches_host_loop(oc, po):
+@pytest.mark.parametrize("which", ["side", "default"])
+def test_stream_ordered_torch_loop_matches_host_loop(oc, po, which):
     """The environment on torch's stream: modes -> action (torch ops) -> step, 30 iterations with no host
-    synchronisation inside the loop, must reproduce the host-synchronous loop."""
+    synchronisation inside the loop, must reproduce the host-synchronous loop -- on a side stream and on torch's
+    default stream (hipStream_t 0: a stream like any other, not "none")."""
+    import contextlib
     import torch
     E_, N, Ng, L, M = 3, 20000, 128, 50.0, 4
     xs, vs = zip(*[po.synthetic_two_stream(N, L, seed=90 + e) for e in range(E_)])
@@ -686,22 +689,24 @@ def test_stream_ordered_torch_loop_matches_host_loop(oc, po):
         env.set_actuator(act)
         env.reset(x0, v0)
     side = torch.cuda.Stream()
-    with torch.cuda.stream(side):                       # a non-default torch stream, shared with the library
+    ctx = torch.cuda.stream(side) if which == "side" else contextlib.nullcontext()
+    with ctx:                                           # the stream shared with the library
         dev.use_torch_stream()
+        assert (torch.cuda.current_stream().cuda_stream == 0) == (which == "default")
         gain = torch.full((1, 2 * M), 0.8, dtype=torch.float64, device="cuda:0")
         total = torch.zeros(E_, dtype=torch.float64, device="cuda:0")
         for _ in range(30):
-            a = dev.feedback_actions_torch(M) * gain    # torch kernels and library kernels interleave on `side`
+            a = dev.feedback_actions_torch(M) * gain    # torch kernels and library kernels interleave on one stream
             dev.step_actions_torch(a)
             total += dev.rewards_torch()
-        side.synchronize()
+        torch.cuda.current_stream().synchronize()
     ret = np.zeros(E_)
     for _ in range(30):
         host.step_actions(host.feedback_actions(M) * 0.8)
         ret += host.rewards()
     (xh, vh), (xd, vd) = host.particles(), dev.particles()
-    assert circ_err(xh, xd, L) / L < 1e-11 and rel_err(vd, vh) < 1e-10
-    assert np.allclose(total.cpu().numpy(), ret, rtol=1e-10)
+    assert np.array_equal(xh, xd) and np.array_equal(vd, vh)         # same integer deposits: same bits
+    assert np.allclose(total.cpu().numpy(), ret, rtol=1e-13)
     dev.use_own_stream()
     dev.step()                                          # still usable on its own stream afterwards
     dev.sync()
