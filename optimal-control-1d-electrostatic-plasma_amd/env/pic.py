@@ -25,7 +25,7 @@ class PIC:
 
     def __init__(self, N: int = 40000, N_mesh: int = 400, n0: float = 1.0, L: float = 50.0, dt: float = 1.0,
                  tmin: float = 0.0, tmax: float = 50.0, gamma: float = 5.0, A: float = 0.1, n_mode: int = 4,
-                 interpol: str = "CIC", init_dist=None, device: int = 0, dtype="float64"):
+                 interpol: str = "CIC", init_dist=None, device: int = 0, dtype="float64", position_dtype=None):
         self.N = N
         self.N_mesh = N_mesh
         self.n0 = n0
@@ -41,6 +41,7 @@ class PIC:
         self.interpol = interpol
         self.device = device
         self.dtype = np.dtype(dtype)
+        self.position_dtype = position_dtype          # None / "float", or "fixed32" with dtype="float32" 
         self._handle = None
         self._handle_key = None
         self._cache = {}
@@ -50,7 +51,7 @@ class PIC:
     # -- device plumbing ---------------------------------------------------------------------
     def _key(self):
         return (self.N, self.N_mesh, float(self.L), float(self.n0), float(self.dt), self.interpol, self.device,
-                str(self.dtype))
+                str(self.dtype), self.position_dtype)
 
     def _ensure_handle(self):
         key = self._key()
@@ -61,7 +62,7 @@ class PIC:
                     carry = self._handle.particles()
                 self._handle.close()
             self._handle = _abi.Handle(self.N, self.N_mesh, 1, self.L, self.n0, self.dt, self.gamma, self.dtype,
-                                       None, self.interpol, self.device)
+                                       None, self.interpol, self.device, position_dtype=self.position_dtype)
             self._handle_key = key
             if carry is not None:
                 self._handle.reset(*carry)

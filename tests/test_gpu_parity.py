@@ -848,6 +848,16 @@ def test_pic_api_corners(oc, po):
     assert s32.x.dtype == np.float64 and s32.get_state().shape == (8000, 1)
     assert abs(s32.get_energy() / float(g["H"][0]) - 1) < 1e-3
     s32.close()
+    # ... and with fixed-point positions (the start is handed over as float32, which bounds what one step can agree to)
+    sfx = oc.PIC(N=int(g["N"]), N_mesh=int(g["Ng"]), n0=float(g["n0"]), L=L, dt=float(g["dt_in"]), gamma=float(g["gamma"]),
+                 A=float(g["A"]), n_mode=int(g["n_mode"]), init_dist=FixedDist(g["x0_raw"], g["v0_raw"]), dtype="float32",
+                 position_dtype="fixed32")
+    sfx.update_state(None)
+    ref1 = po.OraclePIC(g["x0_raw"], g["v0_raw"], int(g["Ng"]), L=L, dt=float(g["dt_in"]), A=float(g["A"]), n_mode=int(g["n_mode"]),
+                        perturb=True, faithful=False)
+    ref1.update_state(None)
+    assert circ_err(sfx.x, ref1.x, L) / L < 3e-7 and rel_err(sfx.v, ref1.v) < 2e-6 and rel_err(sfx.E_mesh, ref1.E_mesh) < 1e-4
+    sfx.close()
     # one-rank ShardedPIC = plain BatchedPIC
     sh = oc.env.sharded.ShardedPIC(3, 5000, 64, L=L, dt=0.1)
     xs, vs = zip(*[po.synthetic_two_stream(5000, L, seed=300 + e) for e in range(3)])
