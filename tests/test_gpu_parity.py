@@ -1002,3 +1002,45 @@ def test_errors_cross_the_abi_as_codes(oc):
     h.reset(x[None], np.zeros((1, 1000)))
     assert h.bad_count() >= 1
     h.close()
+
+
+def test_fixed_point_format_through_the_whole_api(oc, po):
+    """position_dtype="fixed32": every entry point that takes or returns positions converts at the boundary
+    (float32 in, float32 out) and agrees with the float64 handle to what float32 inputs allow."""
+    E_, N, Ng, L = 2, 30_000, 128, 50.0
+    xs, vs = zip(*[po.synthetic_bump_on_tail(N, L, seed=700 + e) for e in range(E_)])
+    x0, v0 = np.stack(xs).astype(np.float32), np.stack(vs).astype(np.float32)
+    x0[x0 >= L] = 0.0
+    fx = oc.BatchedPIC(E_, N, Ng, L=L, dt=0.1, dtype="float32", position_dtype="fixed32")
+    hi = oc.BatchedPIC(E_, N, Ng, L=L, dt=0.1)
+    fx.reset(x0, v0)
+    hi.reset(x0.astype(np.float64), v0.astype(np.float64))
+    # particles come back as float32 within half a float32 ulp of what went in (the fixed-point grid is 327 x finer)
+    xb, vb = fx.particles()
+    assert xb.dtype == np.float32 and np.array_equal(vb, v0) and circ_err(xb, x0, L) <= 2e-6
+    assert rel_err(fx.fields()[1], hi.fields()[1]) < 1e-6 and rel_err(fx.fields()[0], hi.fields()[0]) < 1e-6
+    # probes on arbitrary positions (compute_E), the gather at the particles, CIC bookkeeping
+    xp = np.random.default_rng(1).uniform(-10, 60, (E_, N)).astype(np.float32)          # also outside the box
+    nf, Ef, pf = fx.eval_field(xp)
+    nh, Eh, ph = hi.eval_field(xp.astype(np.float64))
+    assert rel_err(nf, nh) < 1e-6 and rel_err(Ef, Eh) < 1e-5 and np.allclose(pf, ph, rtol=1e-5)
+    assert rel_err(fx.gather_E(), hi.gather_E()) < 1e-5
+    jl, jr, wl, wr = fx._h.cic(1)
+    jl2, jr2, wl2, wr2 = hi._h.cic(1)
+    same = jl == jl2                                     # a particle within 1e-8 of a cell edge may fall on either side
+    assert same.mean() > 0.9999 and np.array_equal(jr[same], jr2[same]) and np.max(np.abs(wr[same] - wr2[same])) < 1e-6
+    assert np.allclose(wl + wr, 1.0, atol=1e-7)
+    # phase-space histogram and Fourier modes of the current state
+    cf, ch = fx._h.phase_histogram(32, -10.0, 10.0), hi._h.phase_histogram(32, -10.0, 10.0)
+    assert np.abs(cf.astype(np.int64) - ch.astype(np.int64)).sum() <= 4 and cf.sum() == ch.sum()
+    fx.step(None, 5)
+    hi.step(None, 5)
+    assert rel_err(fx.modes(3), hi.modes(3)) < 1e-4
+    # zero-copy views: raw uint32 positions and their float64 image
+    fx.sync()
+    t = fx.torch_views()
+    assert str(t["x_fixed"].dtype) == "torch.int32" and t["x"].dtype.is_floating_point
+    assert circ_err(t["x"].cpu().numpy(), fx.particles()[0], L) <= 2e-6
+    assert fx.bad_count() == 0
+    fx.close()
+    hi.close()
