@@ -300,41 +300,112 @@ __device__ __forceinline__ double block_sum(double v, double* ws) {
   return s;
 }
 
+// sums of two values over a workgroup of NW waves at the cost of one (ws: 2 NW doubles of LDS)
+template <int NW>
+__device__ __forceinline__ void block_sum2(double a, double b, double* ws, double& sa, double& sb) {
+  const double wa = wave_sum(a), wb = wave_sum(b);
+  if ((threadIdx.x & 63) == 0) {
+    ws[threadIdx.x >> 6] = wa;
+    ws[NW + (threadIdx.x >> 6)] = wb;
+  }
+  __syncthreads();
+  sa = 0.0;
+  sb = 0.0;
+  for (int i = 0; i < NW; ++i) {
+    sa += ws[i];
+    sb += ws[NW + i];
+  }
+  __syncthreads();
+}
+
 // ---------------------------------------------------------------------------------------------
-// Periodic Poisson solve of one environment by a workgroup of NW waves, in LDS.
+// Periodic Poisson solve of one environment, in LDS.
 // Replaces Gaussian_Elimination_Periodic + the dense grad matvec (src/env/solve.py:27-53, src/env/util.py:99-103,
 // pic.py:116-117).  With G_{j+1/2} = (phi_{j+1}-phi_j)/dx the 3-point periodic Poisson equation reads
 // G_{j+1/2} - G_{j-1/2} = b_j dx, so G = cumsum(b) dx - mean and E_j = -(phi_{j+1}-phi_{j-1})/(2dx)
-// = -(G_{j+1/2} + G_{j-1/2})/2.  In: sb[0..Ng) = b = n - n0.  Out: sb = G_{j+1/2} (mean NOT removed), returns mean(G).
-// Ends with a barrier.
+// = -(G_{j+1/2} + G_{j-1/2})/2; phi_{j+1} = phi_j + dx G_{j+1/2} is a second scan.
+//
+// scan_fields: ONE wave does the scans with shuffles alone (lane l owns the m = ceil(Ng / 64) consecutive nodes from
+// l m) while the other waves of the workgroup go on to the caller's barrier: no barrier inside, and the same
+// rounding whatever the size of the calling workgroup (sweep prologue, resident kernel, field_solve_kernel).
+// In: sb[0..Ng) = b = n - n0.  Out: sb = G_{j+1/2} (mean NOT removed), slot[0] = mean(G); with sp != null also
+// sp[j] = phi_j (before its mean is removed) and slot[1] = mean(phi).  The caller puts a barrier between this call
+// and any use of sb, sp or slot, and does not reuse slot before its next barrier after that.
 // ---------------------------------------------------------------------------------------------
-template <int NW>
-__device__ __forceinline__ double scan_gradient(double* __restrict__ sb, int Ng, double dx, double* __restrict__ ws) {
-  // One wave does both scans with shuffles alone (lane l owns the m = ceil(Ng / 64) consecutive nodes from l m), the
-  // others wait at the barrier: three barriers fewer than a workgroup-wide scan, and the same rounding whatever
-  // the size of the calling workgroup (sweep prologue, resident kernel, field_solve_kernel).
-  const int tid = threadIdx.x;
-  if (tid < 64) {
-    const int m = (Ng + 63) / 64;
-    const int lo = min(tid * m, Ng), hi = min(lo + m, Ng);
-    double loc = 0.0;
-    for (int j = lo; j < hi; ++j) loc += sb[j];
-    double run = wave_incl_scan(loc) - loc;          // exclusive prefix over the lanes
-    loc = 0.0;
-    for (int j = lo; j < hi; ++j) {
-      run += sb[j];
-      const double g = run * dx;
-      sb[j] = g;
-      loc += g;
-    }
-    double tot = loc;
-    for (int off = 32; off > 0; off >>= 1) tot += __shfl_xor(tot, off);
-    if (tid == 0) ws[0] = tot / (double)Ng;
+__device__ __forceinline__ void scan_fields(double* __restrict__ sb, double* __restrict__ sp, int Ng, double dx,
+                                            double* __restrict__ slot) {
+  const int lane = threadIdx.x;
+  if (lane >= 64) return;
+  const int m = (Ng + 63) / 64;
+  const int lo = min(lane * m, Ng), hi = min(lo + m, Ng);
+  double loc = 0.0;
+  for (int j = lo; j < hi; ++j) loc += sb[j];
+  double run = wave_incl_scan(loc) - loc;            // exclusive prefix over the lanes
+  loc = 0.0;
+  for (int j = lo; j < hi; ++j) {
+    run += sb[j];
+    const double g = run * dx;
+    sb[j] = g;
+    loc += g;
   }
-  __syncthreads();                                   // sb holds G everywhere
-  const double gmean = ws[0];
-  __syncthreads();                                   // ws may be reused by the caller
-  return gmean;
+  double tot = loc;
+  for (int off = 32; off > 0; off >>= 1) tot += __shfl_xor(tot, off);
+  const double gmean = tot / (double)Ng;
+  if (lane == 0) slot[0] = gmean;
+  if (sp) {
+    loc = 0.0;
+    for (int j = lo; j < hi; ++j) loc += (sb[j] - gmean) * dx;
+    run = wave_incl_scan(loc) - loc;
+    double ploc = 0.0;
+    for (int j = lo; j < hi; ++j) {
+      sp[j] = run;
+      ploc += run;
+      run += (sb[j] - gmean) * dx;
+    }
+    for (int off = 32; off > 0; off >>= 1) ploc += __shfl_xor(ploc, off);
+    if (lane == 0) slot[1] = ploc / (double)Ng;
+  }
+}
+
+// outputs of a field solve (any pointer may be null) and what goes into them besides the density
+struct SolveOut {
+  const double* ext;       // E_ext [env][Ng] added to E (force evaluations, util.py:102-103), or null
+  double *E, *phi;         // [env][Ng]
+  double *KE, *PE, *PEr;   // [env]
+};
+
+// From sb = b = n - n0 (filled by the caller, barrier included) to E (+ E_ext), zero-mean phi, PE = 0.5 sum(E^2) dx N/L
+// (util.py:129-130), PE_reward = 0.5 sum(E^2) dx (objective.py:33) and KE = 0.5 * (workgroup sum of `ke_share`)
+// (util.py:144), by a workgroup of NW waves.  se: Ng doubles, ws: 2 NW doubles, slot: 2 doubles of LDS.
+template <int NW>
+__device__ __forceinline__ void solve_block(const SolveOut& o, int env, int Ng, double dx, double N_over_L, double ke_share,
+                                            double* __restrict__ sb, double* __restrict__ se, double* __restrict__ ws,
+                                            double* __restrict__ slot) {
+  constexpr int NT = NW * 64;
+  const int tid = threadIdx.x;
+  const size_t row = (size_t)env * Ng;
+  scan_fields(sb, o.phi ? se : nullptr, Ng, dx, slot);
+  __syncthreads();
+  const double gmean = slot[0];
+  const double pmean = o.phi ? slot[1] : 0.0;
+  double e2 = 0.0;
+  for (int j = tid; j < Ng; j += NT) {
+    const double gp = sb[j] - gmean;
+    const double gm = sb[j == 0 ? Ng - 1 : j - 1] - gmean;
+    const double E = -0.5 * (gp + gm);
+    const double Et = o.ext ? E + o.ext[row + j] : E;
+    if (o.E) o.E[row + j] = Et;
+    e2 += Et * Et;
+    if (o.phi) o.phi[row + j] = se[j] - pmean;
+  }
+  double S, K;
+  block_sum2<NW>(e2, ke_share, ws, S, K);
+  if (tid == 0) {
+    const double pe = 0.5 * S * dx;
+    if (o.PEr) o.PEr[env] = pe;
+    if (o.PE) o.PE[env] = pe * N_over_L;
+    if (o.KE) o.KE[env] = 0.5 * K;
+  }
 }
 
 }  // namespace

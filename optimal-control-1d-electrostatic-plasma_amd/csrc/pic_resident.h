@@ -29,19 +29,26 @@ struct ResidentIO {
   double c1, c2, d1, d2;   // Yoshida-4 (integration.py:62-69): c = (c1, c2, c2, c1), d = (0, d1, d2, d1)
 };
 
-// field tile Es (gather layout: Ng + 2 slots, OFF for TSC) from the LDS mesh `acc_all`; sb: Ng doubles of scratch
+// Field tile Es (gather layout: Ng + 2 slots, OFF for TSC) from the LDS mesh `acc_all`; sb: Ng doubles of scratch.
+// While the scanning wave works, the others clear the meshes the coming particle phase deposits into (`z0`, and
+// `z1` = the mesh just read, in sub-stage D), so that the phase needs no barrier of its own for that.
 template <typename T, typename A, int SHAPE, int NW>
 __device__ __forceinline__ void resident_field(const A* __restrict__ acc_all, int R, int stride, const double* __restrict__ ext,
                                                int Ng, int fg, double scale, double n0, double dx, double* __restrict__ sb,
-                                               double* __restrict__ ws, T* __restrict__ Es) {
+                                               double* __restrict__ slot, T* __restrict__ Es, A* __restrict__ z0,
+                                               A* __restrict__ z1) {
   constexpr int NT = NW * 64;
   constexpr int OFF = (SHAPE == PIC_TSC) ? 1 : 0;
   const int tid = threadIdx.x;
   const double unit = ldexp(1.0, -fg);
   for (int j = tid; j < Ng; j += NT)
     sb[j] = ((double)mesh_node_sum<A, SHAPE>(acc_all, R, stride, Ng, fg, j) * unit) * scale - n0;
+  __syncthreads();                                   // the mesh has been read: it may be cleared now
+  scan_fields(sb, nullptr, Ng, dx, slot);
+  for (int i = tid; i < R * stride; i += NT) z0[i] = A{};
+  if (z1) for (int i = tid; i < R * stride; i += NT) z1[i] = A{};
   __syncthreads();
-  const double gmean = scan_gradient<NW>(sb, Ng, dx, ws);
+  const double gmean = slot[0];
   for (int i = tid; i < Ng + 2; i += NT) {
     int node = i - OFF;
     node = node < 0 ? node + Ng : (node >= Ng ? node - Ng : node);
@@ -72,7 +79,8 @@ __global__ __launch_bounds__(NW * 64) void resident_kernel(typename P::X* __rest
   double* sb = reinterpret_cast<double*>(accB + (size_t)R * stride);
   double* se = sb + Ng;
   T* Es = reinterpret_cast<T*>(se + Ng);
-  __shared__ double ws[NW];
+  __shared__ double ws[2 * NW];
+  __shared__ double slot[2];
 
   const int tid = threadIdx.x;
   const int env = blockIdx.x;
@@ -127,10 +135,8 @@ __global__ __launch_bounds__(NW * 64) void resident_kernel(typename P::X* __rest
       // sub-stage st reads the field of the deposit in `in` and deposits into `out` (D: also the next q1 into `in`)
       A* in = (st == ST_C) ? accB : accA;
       A* out = (st == ST_C) ? accA : accB;
-      resident_field<T, A, SHAPE, NW>(in, R, stride, ext, Ng, a.fg, a.scale, a.n0, a.dx, sb, ws, Es);
-      for (int i = tid; i < R * stride; i += NT) out[i] = A{};
-      if (st == ST_D) for (int i = tid; i < R * stride; i += NT) in[i] = A{};
-      __syncthreads();
+      resident_field<T, A, SHAPE, NW>(in, R, stride, ext, Ng, a.fg, a.scale, a.n0, a.dx, sb, slot, Es, out,
+                                      st == ST_D ? in : nullptr);
       // Yoshida coefficients of this sub-stage (integration.py:62-69): (c, d) = (c2, d1), (c3, d2), (c4, d3)
       const T c_cur = (st == ST_D) ? c1 : c2;
       const T d_cur = (st == ST_C) ? d2 : d1;
@@ -179,46 +185,15 @@ __global__ __launch_bounds__(NW * 64) void resident_kernel(typename P::X* __rest
       sb[j] = nj - a.n0;
     }
     __syncthreads();
-    const double gmean = scan_gradient<NW>(sb, Ng, a.dx, ws);
-    double e2 = 0.0;
-    for (int j = tid; j < Ng; j += NT) {
-      const double gp = sb[j] - gmean;
-      const double gm = sb[j == 0 ? Ng - 1 : j - 1] - gmean;
-      const double E = -0.5 * (gp + gm);
-      io.E[row + j] = E;
-      e2 += E * E;
+    SolveOut o{};
+    o.E = io.E; o.phi = io.phi; o.KE = io.KE; o.PE = io.PE; o.PEr = io.PEr;
+    solve_block<NW>(o, env, Ng, a.dx, a.N_over_L, ke, sb, se, ws, slot);
+    if (io.hist && tid == 0) {        // this thread wrote the three energies a moment ago
+      double* h3 = io.hist + (size_t)step * 3 * io.num_envs;
+      h3[env] = io.KE[env];
+      h3[io.num_envs + env] = io.PE[env];
+      h3[2 * (size_t)io.num_envs + env] = io.PEr[env];
     }
-    const double S = block_sum<NW>(e2, ws);
-    const double K = block_sum<NW>(ke, ws);
-    if (tid == 0) {
-      const double pe = 0.5 * S * a.dx;                 // objective.py:33 / util.py:129
-      io.PEr[env] = pe;
-      io.PE[env] = pe * a.N_over_L;                     // util.py:130
-      io.KE[env] = 0.5 * K;                             // util.py:144
-      if (io.hist) {
-        double* slot = io.hist + (size_t)step * 3 * io.num_envs;
-        slot[env] = 0.5 * K;
-        slot[io.num_envs + env] = pe * a.N_over_L;
-        slot[2 * (size_t)io.num_envs + env] = pe;
-      }
-    }
-    {
-      // phi_{j+1} = phi_j + dx G_{j+1/2}: exclusive scan, then remove the mean
-      const int m = (Ng + NT - 1) / NT;
-      const int lo = min(tid * m, Ng), hi = min(lo + m, Ng);
-      double loc = 0.0, tot;
-      for (int j = lo; j < hi; ++j) loc += (sb[j] - gmean) * a.dx;
-      double run = block_excl_scan<NW>(loc, ws, tot);
-      double ploc = 0.0;
-      for (int j = lo; j < hi; ++j) {
-        se[j] = run;
-        ploc += run;
-        run += (sb[j] - gmean) * a.dx;
-      }
-      const double pmean = block_sum<NW>(ploc, ws) / (double)Ng;
-      for (int j = tid; j < Ng; j += NT) io.phi[row + j] = se[j] - pmean;
-    }
-    __syncthreads();
   }
 
 #pragma unroll

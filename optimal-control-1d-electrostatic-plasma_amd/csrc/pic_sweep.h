@@ -12,11 +12,13 @@ namespace {
 template <typename T, int OFF>
 __device__ __forceinline__ void prologue_field(const acc_t* __restrict__ acc_in, const double* __restrict__ ext, int Ng,
                                                double unit, double scale, double n0, double dx,
-                                               double* __restrict__ sb, double* __restrict__ ws, T* __restrict__ Es) {
+                                               double* __restrict__ sb, double* __restrict__ slot, T* __restrict__ Es) {
   const int tid = threadIdx.x;
   for (int j = tid; j < Ng; j += BLOCK) sb[j] = ((double)acc_in[j] * unit) * scale - n0;   // interpolate.py:16-18, pic.py:116
   __syncthreads();
-  const double gmean = scan_gradient<WAVES>(sb, Ng, dx, ws);
+  scan_fields(sb, nullptr, Ng, dx, slot);
+  __syncthreads();
+  const double gmean = slot[0];
   for (int i = tid; i < Ng + 2; i += BLOCK) {
     int node = i - OFF;
     node = node < 0 ? node + Ng : (node >= Ng ? node - Ng : node);
@@ -149,6 +151,7 @@ __global__ __launch_bounds__(BLOCK) void sweep_kernel(typename P::X* __restrict_
   A* acc2_all = acc_all + (size_t)a.R * stride;
   T* Es = reinterpret_cast<T*>(smem_raw + (size_t)2 * a.R * stride * sizeof(A));
   __shared__ double red[WAVES];
+  __shared__ double slot[2];       // mean of the prologue solve's gradient (16 B: keeps the dynamic LDS base aligned)
 
   const int tid = threadIdx.x;
   // Consecutive sweeps walk memory in opposite directions: what the previous sweep wrote last (still
@@ -175,7 +178,7 @@ __global__ __launch_bounds__(BLOCK) void sweep_kernel(typename P::X* __restrict_
 
   if (kGather)
     prologue_field<T, OFF>(io.acc_in + (size_t)env * Ng, io.ext ? io.ext + (size_t)env * Ng : nullptr, Ng,
-                           ldexp(1.0, -a.fg), a.scale, a.n0, a.dx, reinterpret_cast<double*>(smem_raw), red, Es);
+                           ldexp(1.0, -a.fg), a.scale, a.n0, a.dx, reinterpret_cast<double*>(smem_raw), slot, Es);
   for (int c = tid; c < nacc; c += BLOCK) acc_all[c] = A{};
   if (blk == 0) {       // one workgroup per environment clears the retired accumulator rows
     if (io.zero0) for (int c = tid; c < Ng; c += BLOCK) io.zero0[(size_t)env * Ng + c] = 0;

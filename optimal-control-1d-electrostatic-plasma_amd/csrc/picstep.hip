@@ -340,8 +340,8 @@ void launch_solve(pic_handle* h, const SolveIO& io) {
 void launch_final_solve(pic_handle* h, int slot) {
   SolveIO o{};
   o.acc = ring_row(h, slot);
-  o.ke_part = h->ke_part; o.n = h->n; o.E = h->E_mesh; o.phi = h->phi;
-  o.KE = h->KE; o.PE = h->PE; o.PEr = h->PEr;
+  o.ke_part = h->ke_part; o.n = h->n; o.out.E = h->E_mesh; o.out.phi = h->phi;
+  o.out.KE = h->KE; o.out.PE = h->PE; o.out.PEr = h->PEr;
   launch_solve(h, o);
   ring_retire(h, slot);
 }
@@ -948,8 +948,8 @@ static int probe_solve(pic_handle* h, const double* E_ext, bool want_phi) {
   HIPCHK(h, hipMemsetAsync(h->probe_acc, 0, gbytes, h->stream));
   launch_sweep(h, ST_PROBE, h->scratch, h->scratch, 0, 0, 0, -1, nullptr, h->probe_acc, nullptr);
   SolveIO o{};
-  o.acc = h->probe_acc; o.ext = ext; o.n = h->aux_n; o.E = h->aux_E; o.PEr = h->aux_pe;
-  if (want_phi) o.phi = h->aux_phi;
+  o.acc = h->probe_acc; o.out.ext = ext; o.n = h->aux_n; o.out.E = h->aux_E; o.out.PEr = h->aux_pe;
+  if (want_phi) o.out.phi = h->aux_phi;
   launch_solve(h, o);
   HIPCHK(h, hipGetLastError());
   return PIC_OK;
@@ -1030,7 +1030,7 @@ int pic_solve_poisson(pic_handle* h, const double* rhs, double* phi, double* E_m
   const size_t gbytes = (size_t)h->cfg.num_envs * h->cfg.Ng * sizeof(double);
   HIPCHK(h, hipMemcpyAsync(h->aux_n, rhs, gbytes, hipMemcpyHostToDevice, h->stream));
   SolveIO o{};
-  o.rhs = h->aux_n; o.E = h->aux_E; o.phi = h->aux_phi;
+  o.rhs = h->aux_n; o.out.E = h->aux_E; o.out.phi = h->aux_phi;
   launch_solve(h, o);
   HIPCHK(h, hipGetLastError());
   if (phi) HIPCHK(h, hipMemcpyAsync(phi, h->aux_phi, gbytes, hipMemcpyDeviceToHost, h->stream));
