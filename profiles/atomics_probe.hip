@@ -22,7 +22,7 @@ template <int MODE>
 __global__ __launch_bounds__(BLOCK) void probe(double2* __restrict__ a, double2* __restrict__ b, long long n2_env,
                                                long long chunk2, int Ng, int flushes, double* __restrict__ slab,
                                                unsigned long long* __restrict__ acc, double* __restrict__ accd,
-                                               int copy) {
+                                               int copy, int interleave) {
   extern __shared__ unsigned long long mesh[];
   const int env = blockIdx.y, blk = blockIdx.x, nblk = gridDim.x;
   for (int c = threadIdx.x; c < Ng; c += BLOCK) mesh[c] = 0ull;
@@ -31,8 +31,11 @@ __global__ __launch_bounds__(BLOCK) void probe(double2* __restrict__ a, double2*
   if (copy) {
     double2* ae = a + (size_t)env * n2_env;
     double2* be = b + (size_t)env * n2_env;
-    long long begin = (long long)blk * chunk2, end = begin + chunk2 < n2_env ? begin + chunk2 : n2_env;
-    for (long long i = begin + threadIdx.x; i < end; i += BLOCK) {
+    // contiguous: workgroup blk owns [blk chunk2, (blk+1) chunk2); interleaved: tiles blk, blk + nblk, blk + 2 nblk, ...
+    long long begin = interleave ? (long long)blk * BLOCK : (long long)blk * chunk2;
+    long long end = interleave ? n2_env : (begin + chunk2 < n2_env ? begin + chunk2 : n2_env);
+    const long long stride = interleave ? (long long)nblk * BLOCK : BLOCK;
+    for (long long i = begin + threadIdx.x; i < end; i += stride) {
       double2 u = ae[i], w = be[i];
       u.x += 1.0; u.y += 1.0; w.x += 1.0; w.y += 1.0;
       local += (unsigned long long)(long long)u.x;
@@ -61,6 +64,8 @@ __global__ __launch_bounds__(BLOCK) void probe(double2* __restrict__ a, double2*
   }
 }
 
+int g_interleave = 0;
+
 template <int MODE>
 float run(int envs, int nblk, long long n2_env, int Ng, int flushes, int copy, int reps, double2* a, double2* b,
           double* slab, unsigned long long* acc, double* accd) {
@@ -70,10 +75,10 @@ float run(int envs, int nblk, long long n2_env, int Ng, int flushes, int copy, i
   CHK(hipEventCreate(&e0));
   CHK(hipEventCreate(&e1));
   for (int w = 0; w < 3; ++w)
-    hipLaunchKernelGGL(probe<MODE>, grid, dim3(BLOCK), Ng * 8, 0, a, b, n2_env, chunk2, Ng, flushes, slab, acc, accd, copy);
+    hipLaunchKernelGGL(probe<MODE>, grid, dim3(BLOCK), Ng * 8, 0, a, b, n2_env, chunk2, Ng, flushes, slab, acc, accd, copy, g_interleave);
   CHK(hipEventRecord(e0, 0));
   for (int r = 0; r < reps; ++r)
-    hipLaunchKernelGGL(probe<MODE>, grid, dim3(BLOCK), Ng * 8, 0, a, b, n2_env, chunk2, Ng, flushes, slab, acc, accd, copy);
+    hipLaunchKernelGGL(probe<MODE>, grid, dim3(BLOCK), Ng * 8, 0, a, b, n2_env, chunk2, Ng, flushes, slab, acc, accd, copy, g_interleave);
   CHK(hipEventRecord(e1, 0));
   CHK(hipEventSynchronize(e1));
   CHK(hipGetLastError());
@@ -93,6 +98,7 @@ int main(int argc, char** argv) {
     else if (!strcmp(argv[i], "--mesh")) Ng = atoi(argv[++i]);
     else if (!strcmp(argv[i], "--particles")) N = atoll(argv[++i]);
     else if (!strcmp(argv[i], "--reps")) reps = atoi(argv[++i]);
+    else if (!strcmp(argv[i], "--interleave")) g_interleave = 1;
   }
   const long long n2_env = N / 2;                     // double2 elements per env and array
   double2 *a, *b;
