@@ -6,7 +6,7 @@
 namespace {
 
 // Field tile of a sweep workgroup, computed in its own prologue from the accumulator row [Ng] the previous sweep
-// filled: density -> b = n - n0 -> G = dx cumsum(b) -> E_j = -(G_{j+1/2} + G_{j-1/2})/2 + mean (+ E_ext).
+// filled: density -> b = n - n0 -> G = dx cumsum(b) - mean -> E_j = -(G_{j+1/2} + G_{j-1/2})/2 (+ E_ext).
 // Every workgroup of an environment repeats the solve (2 KB of input at Ng = 256, read through L2); in exchange a
 // step has no field-solve launch between its sweeps.  sb: Ng doubles of LDS scratch.
 template <typename T, int OFF>
