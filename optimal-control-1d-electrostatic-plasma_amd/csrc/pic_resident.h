@@ -8,8 +8,8 @@
 // boundary and nothing but the final particles, fields and per-step energies goes to HBM.
 //
 // Arithmetic is the streaming path's, helper by helper (locate, gather_field, drift, deposit, mesh_node_sum,
-// scan_gradient; the gather re-uses the cell and weights the previous deposit located instead of locating the same
-// position again), and the deposits are the same integer sums, so particles and fields come out bit for bit as
+// scan_fields; where registers allow, the gather re-uses the cell and weights the previous deposit located instead of
+// locating the same position again), and the deposits are the same integer sums, so particles and fields come out bit for bit as
 // from the sweeps (tests/test_gpu_resident.py).  Only KE, a float64 sum whose order follows the launch geometry,
 // may differ in its last bits.
 #pragma once
@@ -61,7 +61,7 @@ __device__ __forceinline__ void resident_field(const A* __restrict__ acc_all, in
   __syncthreads();
 }
 
-template <typename P, typename A, int SHAPE, int PPT, int NW>
+template <typename P, typename A, int SHAPE, int PPT, int NW, bool kCarry>
 __global__ __launch_bounds__(NW * 64) void resident_kernel(typename P::X* __restrict__ x, typename P::V* __restrict__ v,
                                                            ResidentIO io, SweepArgs a) {
   constexpr int NT = NW * 64;
@@ -103,17 +103,20 @@ __global__ __launch_bounds__(NW * 64) void resident_kernel(typename P::X* __rest
   }
   unsigned bad = 0u;
 
-  // Where a sub-stage deposits a particle is where the next one gathers its field, so cell and weights of that
-  // position are carried in registers from one sub-stage to the next: one locate per sub-stage instead of two.
-  int js[PPT];
-  T wgt[PPT][SHAPE == PIC_TSC ? 3 : 2];
+  // Where a sub-stage deposits a particle is where the next one gathers its field.  kCarry keeps cell and weights of
+  // that position in registers from one sub-stage to the next (one locate per sub-stage instead of two, -15 % per
+  // step); without it the gather locates again and the kernel needs ~50 registers fewer, so that two workgroups
+  // share a CU -- the better trade once there are more environments than CUs (host: launch_resident).
+  constexpr int NCAR = kCarry ? PPT : 1;
+  int js[NCAR];
+  T wgt[NCAR][SHAPE == PIC_TSC ? 3 : 2];
 
   // deposit of the first drift position q1 = x + (c1 v) dt (integration.py:42 with d1 = 0) into accA
   for (int i = tid; i < 2 * R * stride; i += NT) accA[i] = A{};
   __syncthreads();
 #pragma unroll
   for (int s = 0; s < PPT; ++s) {
-    js[s] = 0;
+    if (kCarry) js[kCarry ? s : 0] = 0;
     if ((long long)s * NT + tid < a.N) {
       T w[3];
       X xw;
@@ -122,9 +125,11 @@ __global__ __launch_bounds__(NW * 64) void resident_kernel(typename P::X* __rest
       const X q = drift<P>(xs[s], vs[s], c1, k, bad);
       locate<P, SHAPE>(q, k, xw, j, w, frac, bad);
       deposit<A, P, SHAPE>(accA + (size_t)rep * stride, j, w, frac, k.magic);
-      js[s] = j;
-      wgt[s][0] = w[0]; wgt[s][1] = w[1];
-      if (SHAPE == PIC_TSC) wgt[s][SHAPE == PIC_TSC ? 2 : 0] = w[2];
+      if (kCarry) {
+        js[kCarry ? s : 0] = j;
+        wgt[kCarry ? s : 0][0] = w[0]; wgt[kCarry ? s : 0][1] = w[1];
+        if (SHAPE == PIC_TSC) wgt[kCarry ? s : 0][SHAPE == PIC_TSC ? 2 : 0] = w[2];
+      }
     }
   }
   __syncthreads();
@@ -147,14 +152,19 @@ __global__ __launch_bounds__(NW * 64) void resident_kernel(typename P::X* __rest
         if ((long long)s * NT + tid < a.N) {
           T w[3];
           X xw;
-          int j = js[s];
+          int j;
           unsigned frac;
           X q = xs[s];
           V p = vs[s];
           if (st == ST_B) q = drift<P>(q, p, c1, k, bad);         // q1 again (it is never stored)
-          w[0] = wgt[s][0]; w[1] = wgt[s][1];
-          w[2] = (SHAPE == PIC_TSC) ? wgt[s][SHAPE == PIC_TSC ? 2 : 0] : T(0);
-          const T E = gather_field<T, SHAPE>(Es, j, w);           // util.py:105 / pic.py:120, at the carried cell / weights
+          if (kCarry) {                                           // cell and weights of q, located by the previous deposit
+            j = js[kCarry ? s : 0];
+            w[0] = wgt[kCarry ? s : 0][0]; w[1] = wgt[kCarry ? s : 0][1];
+            w[2] = (SHAPE == PIC_TSC) ? wgt[kCarry ? s : 0][SHAPE == PIC_TSC ? 2 : 0] : T(0);
+          } else {
+            locate<P, SHAPE>(q, k, xw, j, w, frac, bad);
+          }
+          const T E = gather_field<T, SHAPE>(Es, j, w);           // util.py:105 / pic.py:120
           p = p + (V)((d_cur * (-E)) * k.dt);                     // integration.py:32, pic.py:127
           q = drift<P>(q, p, c_cur, k, bad);                      // integration.py:42
           locate<P, SHAPE>(q, k, xw, j, w, frac, bad);
@@ -167,9 +177,11 @@ __global__ __launch_bounds__(NW * 64) void resident_kernel(typename P::X* __rest
             locate<P, SHAPE>(qn, k, xn, j, w, frac, bad);
             deposit<A, P, SHAPE>(acc2, j, w, frac, k.magic);
           }
-          js[s] = j;
-          wgt[s][0] = w[0]; wgt[s][1] = w[1];
-          if (SHAPE == PIC_TSC) wgt[s][SHAPE == PIC_TSC ? 2 : 0] = w[2];
+          if (kCarry) {
+            js[kCarry ? s : 0] = j;
+            wgt[kCarry ? s : 0][0] = w[0]; wgt[kCarry ? s : 0][1] = w[1];
+            if (SHAPE == PIC_TSC) wgt[kCarry ? s : 0][SHAPE == PIC_TSC ? 2 : 0] = w[2];
+          }
           xs[s] = q;
           vs[s] = p;
         }

@@ -75,6 +75,7 @@ struct pic_handle {
   // resident schedule (pic_resident.h): one workgroup of res_nw waves holds an environment, res_ppt particles per lane
   bool resident = false;
   int res_ppt = 0, res_nw = 0, res_R = 1;
+  bool res_lean = false;          // resident kernel without carried cell / weights (two workgroups per CU)
   size_t res_lds = 0;
   double dx = 0, scale = 0;
   double cs[4]{}, ds[4]{};
@@ -281,8 +282,14 @@ void launch_sweep(pic_handle* h, int stage, void* x, void* v, double c_prev, dou
 
 template <typename P, typename A, int SHAPE, int PPT, int NW>
 void launch_resident_t(pic_handle* h, const ResidentIO& io, const SweepArgs& a) {
-  hipLaunchKernelGGL((resident_kernel<P, A, SHAPE, PPT, NW>), dim3(h->cfg.num_envs), dim3(NW * 64), h->res_lds, h->stream,
-                     static_cast<typename P::X*>(h->x), static_cast<typename P::V*>(h->v), io, a);
+  // More environments than CUs and a slot count whose lean kernel fits 128 registers: two workgroups per CU beat
+  // the 15 % the carried cell / weights save per workgroup (profiles/experiments_r2.md 5).
+  if (h->res_lean)
+    hipLaunchKernelGGL((resident_kernel<P, A, SHAPE, PPT, NW, false>), dim3(h->cfg.num_envs), dim3(NW * 64), h->res_lds,
+                       h->stream, static_cast<typename P::X*>(h->x), static_cast<typename P::V*>(h->v), io, a);
+  else
+    hipLaunchKernelGGL((resident_kernel<P, A, SHAPE, PPT, NW, true>), dim3(h->cfg.num_envs), dim3(NW * 64), h->res_lds,
+                       h->stream, static_cast<typename P::X*>(h->x), static_cast<typename P::V*>(h->v), io, a);
 }
 
 template <typename P, typename A, int SHAPE>
@@ -576,6 +583,9 @@ int pic_create(const pic_config* cfg, pic_handle** out) {
     // large-ish environment is therefore left to the sweeps (they spread it over many CUs).
     const bool worth = cfg->N <= 5120 || cfg->num_envs >= 32;
     h->resident = possible && (cfg->blocks_per_env < 0 || (cfg->blocks_per_env == 0 && worth));
+    int ncu = 256;
+    hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, cfg->device_id);
+    h->res_lean = cfg->num_envs > ncu && h->res_ppt <= 10;
   }
 
 #define CREATE_CHK(call)                                                                      \

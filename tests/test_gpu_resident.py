@@ -30,6 +30,8 @@ CASES = [  # N, Ng, envs, dtype, position_dtype, interpol
     (513, 64, 2, "float64", None, "CIC"),
     (2048, 128, 2, "float64", None, "CIC"),          # exactly full at 4 particles per lane
     (2049, 128, 2, "float64", None, "CIC"),
+    (2500, 100, 300, "float64", None, "CIC"),        # more environments than CUs: the lean kernel (two workgroups per CU)
+    (5000, 250, 260, "float32", "fixed32", "CIC"),
     (8192, 1024, 2, "float64", None, "CIC"),         # the largest resident environment
     (5000, 250, 3, "float32", None, "CIC"),          # packed accumulator
     (5000, 250, 3, "float32", None, "TSC"),
