@@ -188,3 +188,24 @@ def test_bench_line_contract():
     for key in ("value", "unit", "cores", "kind", "sample"):
         assert f'"{key}"' in src, key
     assert "torch.cuda.Event" not in src           # durations come from HIP events on the library's own stream
+
+
+def test_header_is_plain_c(tmp_path):
+    """include/picstep.h is the contract for ANY FFI (cgo, JNI, ctypes ...): it must compile as C99, and a C caller
+    must be able to fill pic_config and take the address of every entry point."""
+    import shutil
+    import subprocess
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no gcc")
+    hdr = os.path.join(ROOT, "include")
+    names = sorted(_abi.SIGNATURES)
+    src = tmp_path / "use_header.c"
+    src.write_text('#include "picstep.h"\n#include <stddef.h>\n'
+                   "int main(void) {\n  pic_config cfg = {0};\n  cfg.N = 1000; cfg.Ng = 64; cfg.num_envs = 1; cfg.L = 50.0; cfg.n0 = 1.0; cfg.dt = 0.1;\n"
+                   "  cfg.particle_dtype = PIC_F32; cfg.position_dtype = PIC_POS_FIXED32; cfg.accum_dtype = PIC_ACC_AUTO; cfg.interpol = PIC_CIC;\n"
+                   "  void* fns[] = {" + ", ".join(f"(void*)&{n}" for n in names) + "};\n"
+                   "  return (int)(sizeof(fns) / sizeof(fns[0])) - " + str(len(names)) + " + (int)(sizeof(cfg) != 80);\n}\n")
+    r = subprocess.run([gcc, "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-Wno-pedantic", "-I", hdr, "-c", str(src), "-o",
+                        str(tmp_path / "use_header.o")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
