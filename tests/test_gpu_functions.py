@@ -192,3 +192,43 @@ def test_integration_md_ctypes_stub_runs_verbatim(oc):
     assert rel_err(n, g["n_1"]) < 1e-12 and rel_err(E, g["E_mesh_1"]) < 1e-11
     H, PE, PEr = st.energies()
     assert abs(H / float(g["H"][1]) - 1) < 1e-12
+
+
+def test_c_program_drives_the_abi(oc, tmp_path):
+    """examples/c_api_demo.c: a plain C process (no Python, no torch) creates a handle, resets, steps and reads back
+    through include/picstep.h; its particles, fields and energies equal the ctypes binding's bit for bit."""
+    import os
+    import shutil
+    import subprocess
+    from conftest import ROOT
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no gcc on this box")
+    lib = oc._abi.library_path()
+    csrc = os.path.dirname(lib)
+    exe = tmp_path / "c_api_demo"
+    cmd = [gcc, "-std=c99", "-O2", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "c_api_demo.c"), "-o", str(exe),
+           "-L", csrc, "-lpicstep", f"-Wl,-rpath,{csrc}", "-Wl,-rpath,/opt/rocm/lib"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    for N, Ng, E_, steps in ((5000, 250, 3, 7), (30000, 128, 2, 4)):        # resident and streaming schedules
+        rng = np.random.default_rng(N)
+        x0, v0 = rng.uniform(0, 50.0, (E_, N)), rng.normal(0, 1.5, (E_, N))
+        inp, out = tmp_path / f"in_{N}.bin", tmp_path / f"out_{N}.bin"
+        ref = oc.BatchedPIC(E_, N, Ng, L=50.0, dt=0.1)
+        with open(inp, "wb") as f:       # the C caller passes dt AFTER the CFL clamp (pic.py:71-73), as the header says
+            f.write(np.int64(N).tobytes() + np.int32(Ng).tobytes() + np.int32(E_).tobytes() + np.float64(50.0).tobytes() + np.float64(ref.dt).tobytes())
+            f.write(x0.tobytes() + v0.tobytes())
+        env = dict(os.environ, LD_LIBRARY_PATH=csrc + ":/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
+        r = subprocess.run([str(exe), str(inp), str(out), str(steps)], capture_output=True, text=True, timeout=120, env=env)
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert ("resident" if N <= 5120 else "streaming") in r.stdout
+        got = np.fromfile(out)
+        ref.reset(x0, v0)
+        ref.step(None, steps)
+        x, v = ref.particles()
+        n, Em, phi = ref.fields()
+        ke, pe, per = ref.energies()
+        want = np.concatenate([a.ravel() for a in (x, v, n, Em, phi, ke, pe, per)])
+        assert got.shape == want.shape and np.array_equal(got, want)
+        ref.close()
