@@ -216,7 +216,7 @@ __device__ __forceinline__ T gather_field(const T* __restrict__ Es, int j, const
 //           independent of the order in which the waves' atomics land: a step is bitwise reproducible.
 //           Rounding a weight to 2^-fg (fg = 38..50 by particle count) is below what one float64 add of
 //           the running sum rounds away.
-//   double  ds_add_f64 (accum_dtype PIC_F64): float64 running sums, order-dependent in the last bits.
+//   double  ds_add_f64 (accum_dtype PIC_ACC_F64): float64 running sums, order-dependent in the last bits.
 //   fix_t   packed (count, sum of w_r) per cell in one word (accum_dtype PIC_FIXED, single-precision CIC):
 //           a particle in cell j adds w_l = 1 - w_r to node j and w_r to node j+1, so per cell the pair
 //           carries the whole deposit, n_j = count_j - S_j + S_{j-1}: ONE ds_add_u64 per particle instead of
