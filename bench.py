@@ -126,6 +126,11 @@ def main():
     ap.add_argument("--accum", default=None, choices=[None, "fix64", "fixed", "float64"])
     ap.add_argument("--positions", default="float", choices=["float", "fixed32"], help="fixed32: 32-bit fixed-point x (float32)")
     ap.add_argument("--blocks-per-env", type=int, default=0)
+    ap.add_argument("--init", default="bump-on-tail", choices=["bump-on-tail", "two-stream"],
+                    help="two-stream: BASELINE config 3's ensemble, drawn by the device sampler")
+    ap.add_argument("--actions", type=int, default=0, metavar="M",
+                    help="a new random action (2M Fourier coefficients in [-1.25, 1.25], SURVEY 8d) for every environment and "
+                         "step, turned into E_ext by the device actuator (BASELINE config 3); 0 = no control")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-procs", type=int, default=1, help="processes (one env each) for the CPU baseline")
     ap.add_argument("--profile-steps", type=int, default=-1, help="steps of the event-bracketed pass (-1 = --steps)")
@@ -168,11 +173,14 @@ def main():
     env = BatchedPIC(E, N, Ng, L=L, dt=0.1, device=dev_index, dtype=args.dtype, accum_dtype=args.accum,
                      blocks_per_env=args.blocks_per_env, position_dtype=args.positions)
     local_rank = dev_index
-    x0, v0 = synth_bump_on_tail_device(torch, E, N, L, tdtype, f"cuda:{local_rank}", seed=1234 + rank)
-    torch.cuda.synchronize()
-    env.reset_device(x0.data_ptr(), v0.data_ptr())
-    env.sync()
-    del x0, v0
+    if args.init == "two-stream":
+        env.reset_sampled("two-stream", v0=3.0, sigma=1.0, A=0.1, n_mode=2, seed=1234 + rank)
+    else:
+        x0, v0 = synth_bump_on_tail_device(torch, E, N, L, tdtype, f"cuda:{local_rank}", seed=1234 + rank)
+        torch.cuda.synchronize()
+        env.reset_device(x0.data_ptr(), v0.data_ptr())
+        env.sync()
+        del x0, v0
     ke0, pe0, _ = env.energies()
 
     def barrier():
@@ -181,7 +189,25 @@ def main():
         torch.cuda.synchronize()
         env.sync()
 
-    env.step(None, nsteps=args.warmup)
+    acts = None
+    if args.actions > 0:
+        from ocplasma_amd.control.actuator import E_field
+        env.set_actuator(E_field(L, Ng, args.actions))
+        g = torch.Generator(device=f"cuda:{local_rank}")
+        g.manual_seed(4321 + rank)
+        nact = max(args.steps, args.warmup, 1)
+        acts = (torch.rand((nact, E, 2 * args.actions), generator=g, device=f"cuda:{local_rank}", dtype=torch.float64) * 2.5 - 1.25)
+        torch.cuda.synchronize()
+
+    def run_steps(k):
+        """k environment steps: one pic_step call, or (with --actions) k calls that each build E_ext from a new action."""
+        if acts is None:
+            env.step(None, nsteps=k)
+        else:
+            for i in range(k):
+                env.step_actions_device(acts[i].data_ptr(), 1)
+
+    run_steps(args.warmup)
     if dist is not None:
         # RCCL sets a collective up on its first use: run the ones of the timed region once, untimed
         w = torch.as_tensor(env.rewards(), device=cdev)
@@ -189,7 +215,7 @@ def main():
         dist.all_reduce(torch.zeros(1, device=cdev, dtype=torch.float64), op=dist.ReduceOp.MAX)
     barrier()
     t0 = time.perf_counter()
-    env.step(None, nsteps=args.steps)
+    run_steps(args.steps)
     env.sync()
     t_steps = time.perf_counter() - t0              # this rank's K steps, before any collective
     returns = torch.as_tensor(env.rewards(), device=cdev)
@@ -229,7 +255,7 @@ def main():
         env.profile(True)
         env.sync()
         t1 = time.perf_counter()
-        env.step(None, nsteps=psteps)
+        run_steps(min(psteps, args.steps) if acts is not None else psteps)
         env.sync()
         ms_per_step_events = (time.perf_counter() - t1) / psteps * 1e3
         prof = env.profile_read()
@@ -264,9 +290,10 @@ def main():
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f64" if args.dtype == "float64" else "f32", "data": "synthetic",
         "config": {"workload": f"{'configs[1]: ' if (N, Ng, E, args.dtype) == (1_000_000, 256, 64, 'float64') else ''}"
-                               f"bump-on-tail, N={N}, Ng={Ng}, {E} envs per GPU, {args.dtype}"
+                               f"{args.init}, N={N}, Ng={Ng}, {E} envs per GPU, {args.dtype}"
                                f"{' (fixed-point positions)' if args.positions == 'fixed32' else ''}, "
-                               "no control (E_ext = None), Yoshida-4 step = PIC.update_state",
+                               + (f"a new random action of {2 * args.actions} coefficients per step through the device actuator"
+                                  if args.actions > 0 else "no control (E_ext = None)") + ", Yoshida-4 step = PIC.update_state",
                    "envs_per_gpu": E, "particles_per_env": N, "mesh": Ng, "dt": env.dt, "schedule": env._h.schedule(),
                    "sharding": f"{world} x {E} envs, all-gather of returns only"},
         # whole-step fractions of the 8 TB/s peak: on the bytes the schedule really moves (12 words per particle-step)

@@ -11,8 +11,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CASES = [
     ("config 1: N=1e4, Ng=128, 1 env, fp64 (sweeps)", "--steps 2000 --warmup 200 --envs 1 --particles 10000 --mesh 128"),
     ("config 2: N=1e6, Ng=256, 64 envs, fp64", "--steps 50 --warmup 5"),
-    ("config 3 shape: N=1e6, Ng=512, 128 envs, fp32 x and v (no actions here)", "--steps 50 --warmup 5 --envs 128 --mesh 512 --dtype float32"),
-    ("config 3 shape, fixed-point positions", "--steps 50 --warmup 5 --envs 128 --mesh 512 --dtype float32 --positions fixed32"),
+    ("config 3: two-stream, N=1e6, Ng=512, 128 envs, fp32 x and v, a new random action every step", "--steps 50 --warmup 5 --envs 128 --mesh 512 --dtype float32 --init two-stream --actions 3"),
+    ("config 3 with fixed-point positions", "--steps 50 --warmup 5 --envs 128 --mesh 512 --dtype float32 --positions fixed32 --init two-stream --actions 3"),
+    ("config 3 shape without control (one pic_step call for all steps)", "--steps 50 --warmup 5 --envs 128 --mesh 512 --dtype float32 --positions fixed32"),
     ("config 4 share: N=4e6, Ng=1024, 64 envs, fp64", "--steps 20 --warmup 3 --particles 4000000 --mesh 1024"),
     ("config 5 share: N=1e7, Ng=256, 128 envs, fp32 push / fp64 mesh", "--steps 10 --warmup 2 --envs 128 --particles 10000000 --dtype float32"),
     ("config 5 share, fixed-point positions", "--steps 10 --warmup 2 --envs 128 --particles 10000000 --dtype float32 --positions fixed32"),
