@@ -170,6 +170,25 @@ class BatchedPIC:
             self._views = self.torch_views()
         return torch.clamp(1.0 - self._views["PE_reward"], min=0.0)
 
+    def trainer_rewards_torch(self, actions=None, alpha: float = 1.0, beta: float = 1.0, r_pe_n: float = 1.0,
+                              r_ie_n: Optional[float] = None):
+        """Reward.compute_reward (src/control/rl/reward.py:71-76) for every environment, on the device:
+        alpha max(1 - PE_r / r_pe_n, 0) + beta max(1 - (sum a^2 L / 4) / r_ie_n, 0), with PE_r the field energy of the
+        CURRENT state (read before stepping, it is the pre-step reward the trainers use, ddpg.py:455) and `actions` the
+        [num_envs, A] CUDA tensor about to be applied.  r_ie_n defaults to the reference's normaliser, the input energy of
+        an all-ones action of the same length (reward.py:26)."""
+        import torch
+        if not hasattr(self, "_views"):
+            self._views = self.torch_views()
+        r = alpha * torch.clamp(1.0 - self._views["PE_reward"] / r_pe_n, min=0.0)
+        if actions is not None and beta != 0.0:
+            a = actions.to(torch.float64)
+            ie = (a * a).sum(dim=1) * (self.L * 0.25)
+            if r_ie_n is None:
+                r_ie_n = a.shape[1] * self.L * 0.25
+            r = r + beta * torch.clamp(1.0 - ie / r_ie_n, min=0.0)
+        return r
+
     def phase_density(self, nbins: int, vmin: float = -25.0, vmax: float = 25.0):
         """estimate_f (src/control/objective.py:8-14) for every environment, [num_envs, nbins, nbins]:
         the histogram is counted on the device, the normalisation n0/dx/dv/N applied here."""

@@ -1044,3 +1044,25 @@ def test_fixed_point_format_through_the_whole_api(oc, po):
     assert fx.bad_count() == 0
     fx.close()
     hi.close()
+
+
+def test_trainer_reward_on_device_matches_reward_class(oc, po):
+    """BatchedPIC.trainer_rewards_torch = Reward.compute_reward (reward.py:71-76) per environment, without the host
+    round trip and the second deposit the reference's reward needs (golden g4 pins Reward itself)."""
+    import torch
+    E_, N, Ng, L, M = 4, 20000, 128, 50.0, 5
+    xs, vs = zip(*[po.synthetic_two_stream(N, L, seed=800 + e) for e in range(E_)])
+    env = oc.BatchedPIC(E_, N, Ng, L=L, dt=0.1)
+    env.reset(np.stack(xs), np.stack(vs))
+    env.step(None, 30)
+    env.sync()
+    actions = np.random.default_rng(4).uniform(-1.25, 1.25, (E_, 2 * M))
+    got = env.trainer_rewards_torch(torch.as_tensor(actions, device="cuda:0"), alpha=0.7, beta=1.3).cpu().numpy()
+    x, v = env.particles()
+    for e in range(E_):
+        st = np.concatenate([x[e], v[e]]).reshape(-1, 1)
+        rew = oc.Reward(st, Ng, L, -25.0, 25.0, 1.0, 0.7, 1.3, n_actions=2 * M)
+        assert abs(got[e] - rew.compute_reward(st, actions[e])) < 1e-9          # Reward re-deposits the host state
+        assert abs(got[e] - rew.reward_from_energy(env.energies()[2][e], actions[e])) < 1e-13
+    assert np.allclose(env.trainer_rewards_torch().cpu().numpy(), env.rewards(), rtol=1e-14)
+    env.close()
