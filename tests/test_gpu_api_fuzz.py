@@ -5,7 +5,9 @@ accumulator rows with its clean / retired bookkeeping, an open staged step, whic
 every entry point may be called in any order the header allows.  Each sequence mixes steps (with and without an
 external field, one or several per call), staged steps, energy histories, resets, particle loads followed by
 refresh / invalidate / nothing, probes in the middle of everything, and checks particles, fields and energies
-against the oracle (src/env/pic.py:131-146 restated) after every state-changing call."""
+against the oracle (src/env/pic.py:131-146 restated) after every state-changing call.  Mesh sizes are ones for which
+the reference's own periodic solve is regular at L = 50 (it is singular e.g. for Ng = 8, 64, 100: DESIGN.md 2); a one-off
+run of 80 further seeds over ten shapes passed as well (profiles/experiments_r2.md)."""
 import numpy as np
 import pytest
 
