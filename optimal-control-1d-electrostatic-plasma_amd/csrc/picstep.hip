@@ -585,7 +585,8 @@ int pic_create(const pic_config* cfg, pic_handle** out) {
     h->resident = possible && (cfg->blocks_per_env < 0 || (cfg->blocks_per_env == 0 && worth));
     int ncu = 256;
     hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, cfg->device_id);
-    h->res_lean = cfg->num_envs > ncu && h->res_ppt <= 10;
+    // (carrying three TSC weights for 16 particles per lane would need more than 256 registers)
+    h->res_lean = (cfg->num_envs > ncu && h->res_ppt <= 10) || (cfg->interpol == PIC_TSC && h->res_ppt == 16);
   }
 
 #define CREATE_CHK(call)                                                                      \
