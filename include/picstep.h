@@ -161,6 +161,13 @@ int pic_step_stage(pic_handle* h, int stage, const double* E_ext, int mem_kind);
  * No host synchronisation between the steps; returns when the history has arrived. */
 int pic_step_history(pic_handle* h, const double* E_ext, int mem_kind, int nsteps, double* hist);
 
+/* The same with the particle snapshots PIC.simulate returns as well (pic.py:175-223): snap, host
+ * [nsteps][2][num_envs][N] of the particle dtype = positions (wrapped, in length units whatever the position format)
+ * and velocities after each step; hist as in pic_step_history, or NULL.  The snapshots stay on the device until the
+ * end of the call (PIC_ENOMEM if nsteps of them do not fit: record in several calls); in the resident schedule the
+ * kernel writes them from its registers, one launch for all steps. */
+int pic_step_snapshots(pic_handle* h, const double* E_ext, int mem_kind, int nsteps, void* snap, double* hist);
+
 /* compute_E with everything it can return (src/env/util.py:73-116, return_all=True) and the shape-function
  * bookkeeping of compute_n / CIC / TSC (util.py:48-70, src/env/interpolate.py:4-44), on arbitrary positions.
  * x: [num_envs][N] particle dtype (host or device); E_ext: NULL or host [num_envs][Ng] float64.  Host outputs,

@@ -51,6 +51,7 @@ SIGNATURES = {
     "pic_step": [_vp, _vp, C.c_int, C.c_int],
     "pic_step_stage": [_vp, C.c_int, _vp, C.c_int],
     "pic_step_history": [_vp, _vp, C.c_int, C.c_int, _vp],
+    "pic_step_snapshots": [_vp, _vp, C.c_int, C.c_int, _vp, _vp],
     "pic_get_particles": [_vp, _vp, _vp, C.c_int],
     "pic_set_particles": [_vp, _vp, _vp, C.c_int],
     "pic_refresh": [_vp],
@@ -278,6 +279,15 @@ class Handle:
         hist = np.empty((int(nsteps), 3, self.num_envs))
         self._chk(self.lib.pic_step_history(self._h, _ptr(e), PIC_HOST, int(nsteps), _ptr(hist)))
         return hist[:, 0], hist[:, 1], hist[:, 2]
+
+    def step_snapshots(self, E_ext=None, nsteps=1):
+        """nsteps steps; returns (x, v, KE, PE, PE_reward): particles after every step [nsteps][num_envs][N] and the
+        energies [nsteps][num_envs] -- what PIC.simulate records, with one read-back at the end."""
+        e = None if E_ext is None else np.ascontiguousarray(np.asarray(E_ext, dtype=np.float64).reshape(self.num_envs, self.Ng))
+        snap = np.empty((int(nsteps), 2, self.num_envs, self.N), dtype=self.dtype)
+        hist = np.empty((int(nsteps), 3, self.num_envs))
+        self._chk(self.lib.pic_step_snapshots(self._h, _ptr(e), PIC_HOST, int(nsteps), _ptr(snap), _ptr(hist)))
+        return snap[:, 0], snap[:, 1], hist[:, 0], hist[:, 1], hist[:, 2]
 
     def compute_E(self, x, E_ext=None, particles=True, shape=False):
         """compute_E(return_all=True) + shape bookkeeping on arbitrary positions.  Returns a dict with

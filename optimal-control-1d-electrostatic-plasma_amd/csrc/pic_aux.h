@@ -5,24 +5,6 @@
 
 namespace {
 
-// position formats <-> length units
-template <typename P>
-__device__ __forceinline__ double pos_to_length(typename P::X q, double L) {
-  if constexpr (P::kFixed) return (double)q * (L * 2.3283064365386963e-10);     // u L / 2^32
-  else return (double)q;
-}
-
-template <typename P>
-__device__ __forceinline__ typename P::X pos_from_length(double xs, double L, unsigned& bad) {
-  if constexpr (P::kFixed) {
-    double r = xs - floor(xs / L) * L;                 // np.mod for any finite xs
-    if (!(r >= 0.0 && r < L)) { if (!(r == L)) bad += 1u; r = 0.0; }
-    return (unsigned)((unsigned long long)rint(r / L * 4294967296.0) & 0xFFFFFFFFull);
-  } else {
-    return (typename P::X)xs;
-  }
-}
-
 // PIC.E (pic.py:120) and the CIC bookkeeping attributes (pic.py:104-107), on demand.
 template <typename P, int SHAPE>
 __global__ __launch_bounds__(BLOCK) void gather_E_kernel(const typename P::X* __restrict__ x,
@@ -106,6 +88,24 @@ __global__ __launch_bounds__(BLOCK) void positions_out_kernel(const typename P::
     F f = (F)pos_to_length<P>(src[(size_t)env * ld + i], L);
     if (f >= (F)L) f = F(0);
     dst[(size_t)env * N + i] = f;
+  }
+}
+
+// particles of the step just finished -> slot `s` of a snapshot array [steps][2][num_envs][N] (floats of the particle dtype)
+template <typename P>
+__global__ __launch_bounds__(BLOCK) void record_particles_kernel(const typename P::X* __restrict__ x,
+                                                                 const typename P::V* __restrict__ v,
+                                                                 typename P::V* __restrict__ snap, int s, long long N,
+                                                                 long long ld, double L) {
+  using F = typename P::V;
+  const int env = blockIdx.y, E = gridDim.y;
+  F* sx = snap + ((size_t)s * 2 * E + env) * (size_t)N;
+  F* sv = sx + (size_t)E * (size_t)N;
+  for (long long i = (long long)blockIdx.x * BLOCK + threadIdx.x; i < N; i += (long long)gridDim.x * BLOCK) {
+    F xf = (F)pos_to_length<P>(x[(size_t)env * ld + i], L);
+    if (P::kFixed && xf >= (F)L) xf = F(0);
+    sx[i] = xf;
+    sv[i] = v[(size_t)env * ld + i];
   }
 }
 

@@ -187,6 +187,24 @@ __device__ __forceinline__ void locate(typename P::X q, const Consts<P>& k, type
   }
 }
 
+// position formats <-> length units
+template <typename P>
+__device__ __forceinline__ double pos_to_length(typename P::X q, double L) {
+  if constexpr (P::kFixed) return (double)q * (L * 2.3283064365386963e-10);     // u L / 2^32
+  else return (double)q;
+}
+
+template <typename P>
+__device__ __forceinline__ typename P::X pos_from_length(double xs, double L, unsigned& bad) {
+  if constexpr (P::kFixed) {
+    double r = xs - floor(xs / L) * L;                 // np.mod for any finite xs
+    if (!(r >= 0.0 && r < L)) { if (!(r == L)) bad += 1u; r = 0.0; }
+    return (unsigned)((unsigned long long)rint(r / L * 4294967296.0) & 0xFFFFFFFFull);
+  } else {
+    return (typename P::X)xs;
+  }
+}
+
 // q + (c p) dt  (integration.py:42).  PosU32: the displacement is rounded to position units and added modulo
 // 2^32, which is the periodic wrap; a displacement of half a box or more per sub-stage cannot be represented
 // (and is far outside any CFL-limited step): counted as a bad position.

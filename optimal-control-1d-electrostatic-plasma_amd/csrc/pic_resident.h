@@ -23,6 +23,7 @@ struct ResidentIO {
   double *n, *E, *phi;     // [env][Ng] post-step refresh of the LAST step (pic.py:145-146)
   double *KE, *PE, *PEr;   // [env]
   double* hist;            // [nsteps][3][env] KE, PE, PE_reward after every step, or null
+  void* snap;              // [nsteps][2][env][N] positions (as floats of the particle dtype) and velocities after every step, or null
   unsigned long long* bad;
   int nsteps;
   int num_envs;
@@ -200,6 +201,21 @@ __global__ __launch_bounds__(NW * 64) void resident_kernel(typename P::X* __rest
     SolveOut o{};
     o.E = io.E; o.phi = io.phi; o.KE = io.KE; o.PE = io.PE; o.PEr = io.PEr;
     solve_block<NW>(o, env, Ng, a.dx, a.N_over_L, ke, sb, se, ws, slot);
+    if (io.snap) {                    // PIC.simulate's particle snapshots (pic.py:175-223), written from the registers
+      using F = typename P::V;        // positions leave as floats of the particle dtype whatever their format
+      F* sx = static_cast<F*>(io.snap) + ((size_t)step * 2 * io.num_envs + env) * (size_t)a.N;
+      F* sv = sx + (size_t)io.num_envs * (size_t)a.N;
+#pragma unroll
+      for (int s = 0; s < PPT; ++s) {
+        const long long i = (long long)s * NT + tid;
+        if (i < a.N) {
+          F xf = (F)pos_to_length<P>(xs[s], a.L);
+          if (P::kFixed && xf >= (F)a.L) xf = F(0);
+          sx[i] = xf;
+          sv[i] = vs[s];
+        }
+      }
+    }
     if (io.hist && tid == 0) {        // this thread wrote the three energies a moment ago
       double* h3 = io.hist + (size_t)step * 3 * io.num_envs;
       h3[env] = io.KE[env];

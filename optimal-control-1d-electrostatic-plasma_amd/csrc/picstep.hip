@@ -313,7 +313,7 @@ void launch_resident_p(pic_handle* h, const ResidentIO& io, const SweepArgs& a) 
 }
 
 // nsteps environment steps in one launch of the resident schedule; hist: device [nsteps][3][env] or null
-void launch_resident(pic_handle* h, const double* ext, int nsteps, double* hist) {
+void launch_resident(pic_handle* h, const double* ext, int nsteps, double* hist, void* snap = nullptr) {
   SweepArgs a{};
   a.N = h->cfg.N; a.ld = h->ld; a.Ng = h->cfg.Ng; a.R = h->res_R;
   a.fg = h->fg; a.magic = h->magic;
@@ -325,7 +325,7 @@ void launch_resident(pic_handle* h, const double* ext, int nsteps, double* hist)
   ResidentIO io{};
   io.ext = ext;
   io.n = h->n; io.E = h->E_mesh; io.phi = h->phi; io.KE = h->KE; io.PE = h->PE; io.PEr = h->PEr;
-  io.hist = hist; io.bad = h->bad; io.nsteps = nsteps; io.num_envs = h->cfg.num_envs;
+  io.hist = hist; io.snap = snap; io.bad = h->bad; io.nsteps = nsteps; io.num_envs = h->cfg.num_envs;
   io.c1 = h->cs[0]; io.c2 = h->cs[1]; io.d1 = h->ds[1]; io.d2 = h->ds[2];
   prof_begin(h, 6);
   if (h->fmt == FMT_F64) launch_resident_p<PosF64>(h, io, a);
@@ -799,44 +799,81 @@ int pic_step(pic_handle* h, const double* E_ext, int mem_kind, int nsteps) {
   return PIC_OK;
 }
 
-int pic_step_history(pic_handle* h, const double* E_ext, int mem_kind, int nsteps, double* hist) {
-  if (!h || !hist) return fail(h, PIC_EINVAL, "pic_step_history: null argument");
-  if (nsteps < 0) return fail(h, PIC_EINVAL, "pic_step_history: nsteps < 0");
+// nsteps steps with the energies (hist, may be null) and / or the particles (snap, may be null) of every step kept on
+// the device and read back once at the end
+static int step_recording(pic_handle* h, const double* E_ext, int mem_kind, int nsteps, double* hist, void* snap,
+                          const char* who) {
+  if (nsteps < 0) return fail(h, PIC_EINVAL, std::string(who) + ": nsteps < 0");
   if (nsteps == 0) return PIC_OK;
+  if (!h->has_state) return fail(h, PIC_ESTATE, std::string(who) + ": call pic_reset first");
+  if (h->mid_stage) return fail(h, PIC_ESTATE, std::string(who) + ": a staged step is in progress (finish pic_step_stage 1..3)");
   HIPCHK(h, hipSetDevice(h->cfg.device_id));
   const int E = h->cfg.num_envs;
-  const size_t bytes = (size_t)nsteps * 3 * E * sizeof(double);
+  const size_t hbytes = (size_t)nsteps * 3 * E * sizeof(double);
+  const size_t sbytes = (size_t)nsteps * 2 * E * (size_t)h->cfg.N * h->esz;
   double* dh = nullptr;
-  HIPCHK(h, hipMalloc((void**)&dh, bytes));
+  void* ds = nullptr;
+  if (hist && hipMalloc((void**)&dh, hbytes) != hipSuccess) return fail(h, PIC_ENOMEM, std::string(who) + ": history buffer");
+  if (snap && hipMalloc(&ds, sbytes) != hipSuccess) {
+    if (dh) hipFree(dh);
+    return fail(h, PIC_ENOMEM, std::string(who) + ": the snapshots of all steps do not fit on the device; record fewer steps per call");
+  }
   // the external field is uploaded once; the per-step calls then take it from the device
   const double* ext = E_ext;
   int kind = mem_kind;
   int rc = PIC_OK;
+  hipError_t e = hipSuccess;
   if (E_ext && mem_kind == PIC_HOST) {
-    hipError_t e = hipMemcpyAsync(h->ext, E_ext, (size_t)E * h->cfg.Ng * sizeof(double), hipMemcpyHostToDevice, h->stream);
-    if (e != hipSuccess) { hipFree(dh); return fail(h, PIC_EHIP, std::string("pic_step_history: ") + hipGetErrorString(e)); }
+    e = hipMemcpyAsync(h->ext, E_ext, (size_t)E * h->cfg.Ng * sizeof(double), hipMemcpyHostToDevice, h->stream);
     ext = h->ext;
     kind = PIC_DEVICE;
   }
-  if (h->resident && h->has_state && !h->mid_stage) {
-    launch_resident(h, ext, nsteps, dh);        // the kernel records the energies of every step itself
-    drop_cached_deposits(h);
-  } else {
-    for (int s = 0; s < nsteps && rc == PIC_OK; ++s) {
-      rc = pic_step(h, ext, kind, 1);
-      if (rc == PIC_OK)
-        hipLaunchKernelGGL(record_energies_kernel, dim3((E + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, h->stream, h->KE, h->PE,
-                           h->PEr, dh, s, E);
+  if (e == hipSuccess) {
+    if (h->resident) {
+      launch_resident(h, ext, nsteps, dh, ds);        // the kernel records every step itself
+      drop_cached_deposits(h);
+    } else {
+      const dim3 grid = aux_grid(h, E);
+      for (int s = 0; s < nsteps && rc == PIC_OK; ++s) {
+        rc = pic_step(h, ext, kind, 1);
+        if (rc != PIC_OK) break;
+        if (dh)
+          hipLaunchKernelGGL(record_energies_kernel, dim3((E + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, h->stream, h->KE, h->PE,
+                             h->PEr, dh, s, E);
+        if (ds) {
+          if (h->fmt == FMT_F64)
+            hipLaunchKernelGGL(record_particles_kernel<PosF64>, grid, dim3(BLOCK), 0, h->stream, (const double*)h->x,
+                               (const double*)h->v, (double*)ds, s, h->cfg.N, h->ld, h->cfg.L);
+          else if (h->fmt == FMT_F32)
+            hipLaunchKernelGGL(record_particles_kernel<PosF32>, grid, dim3(BLOCK), 0, h->stream, (const float*)h->x,
+                               (const float*)h->v, (float*)ds, s, h->cfg.N, h->ld, h->cfg.L);
+          else
+            hipLaunchKernelGGL(record_particles_kernel<PosU32>, grid, dim3(BLOCK), 0, h->stream, (const unsigned*)h->x,
+                               (const float*)h->v, (float*)ds, s, h->cfg.N, h->ld, h->cfg.L);
+        }
+      }
     }
+    e = hipGetLastError();
   }
-  hipError_t e = hipGetLastError();
-  if (rc == PIC_OK && e == hipSuccess) e = hipMemcpyAsync(hist, dh, bytes, hipMemcpyDeviceToHost, h->stream);
+  if (rc == PIC_OK && e == hipSuccess && dh) e = hipMemcpyAsync(hist, dh, hbytes, hipMemcpyDeviceToHost, h->stream);
+  if (rc == PIC_OK && e == hipSuccess && ds) e = hipMemcpyAsync(snap, ds, sbytes, hipMemcpyDeviceToHost, h->stream);
   hipError_t e2 = hipStreamSynchronize(h->stream);
-  hipFree(dh);
+  if (dh) hipFree(dh);
+  if (ds) hipFree(ds);
   if (rc != PIC_OK) return rc;
   if (e != hipSuccess || e2 != hipSuccess)
-    return fail(h, PIC_EHIP, std::string("pic_step_history: ") + hipGetErrorString(e != hipSuccess ? e : e2));
+    return fail(h, PIC_EHIP, std::string(who) + ": " + hipGetErrorString(e != hipSuccess ? e : e2));
   return PIC_OK;
+}
+
+int pic_step_history(pic_handle* h, const double* E_ext, int mem_kind, int nsteps, double* hist) {
+  if (!h || !hist) return fail(h, PIC_EINVAL, "pic_step_history: null argument");
+  return step_recording(h, E_ext, mem_kind, nsteps, hist, nullptr, "pic_step_history");
+}
+
+int pic_step_snapshots(pic_handle* h, const double* E_ext, int mem_kind, int nsteps, void* snap, double* hist) {
+  if (!h || !snap) return fail(h, PIC_EINVAL, "pic_step_snapshots: null argument");
+  return step_recording(h, E_ext, mem_kind, nsteps, hist, snap, "pic_step_snapshots");
 }
 
 int pic_get_particles(pic_handle* h, void* x, void* v, int mem_kind) {

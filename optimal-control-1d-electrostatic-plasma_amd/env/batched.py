@@ -64,6 +64,12 @@ class BatchedPIC:
         ke, pe, _ = self._h.step_history(E_external, nsteps)
         return np.concatenate([(ke0 + pe0)[None], ke + pe]), np.concatenate([pe0[None], pe])
 
+    def simulate_snapshots(self, nsteps: int, E_external: Optional[np.ndarray] = None):
+        """PIC.simulate's snapshots for every environment: (x, v) after each step, each [nsteps, num_envs, N] of the
+        particle dtype, and (KE, PE, PE_reward) [nsteps, num_envs]; one read-back for all steps (mind the size:
+        nsteps x 2 x num_envs x N values are held on the device until the end of the call)."""
+        return self._h.step_snapshots(E_external, nsteps)
+
     def step_history(self, E_external: Optional[np.ndarray] = None, nsteps: int = 1):
         """nsteps x update_state; -> (KE, PE, PE_reward) after every step, each [nsteps, num_envs]."""
         return self._h.step_history(E_external, nsteps)

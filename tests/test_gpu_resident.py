@@ -139,3 +139,58 @@ def test_resident_schedule_limits(oc):
     assert oc.BatchedPIC(1, 8000, 128)._h.schedule() == "streaming"
     assert oc.BatchedPIC(64, 8000, 128)._h.schedule() == "resident"
     assert oc.BatchedPIC(1, 1000, 64, accum_dtype="float64")._h.schedule() == "streaming"
+
+
+@pytest.mark.parametrize("N,Ng,bpe,dtype,pos", [(5000, 250, 0, "float64", None), (5000, 250, 2, "float64", None),
+                                                (30000, 128, 0, "float64", None), (3000, 96, 0, "float32", "fixed32"),
+                                                (3000, 96, 2, "float32", "fixed32")])
+def test_snapshots_of_every_step_equal_stepwise_reads(oc, N, Ng, bpe, dtype, pos):
+    """pic_step_snapshots (what PIC.simulate records, pic.py:175-223): particles and energies of every step, kept on the
+    device and read back once -- equal to stepping one step at a time and reading after each, in both schedules."""
+    E_, K, L = 3, 6, 50.0
+    rng = np.random.default_rng(N)
+    x0 = rng.uniform(0, L, (E_, N)).astype(dtype)
+    x0[x0 >= L] = 0.0
+    v0 = rng.normal(0, 1.3, (E_, N)).astype(dtype)
+    ext = 0.05 * rng.normal(size=(E_, Ng))
+    kw = dict(L=L, dt=0.1, dtype=dtype, position_dtype=pos, blocks_per_env=bpe)
+    a, b = oc.BatchedPIC(E_, N, Ng, **kw), oc.BatchedPIC(E_, N, Ng, **kw)
+    for env in (a, b):
+        env.reset(x0, v0)
+    xs, vs, ke, pe, per = a.simulate_snapshots(K, ext)
+    assert xs.shape == vs.shape == (K, E_, N) and ke.shape == (K, E_) and xs.dtype == np.dtype(dtype)
+    for k in range(K):
+        b.step(ext)
+        xb, vb = b.particles()
+        kb, pb, rb = b.energies()
+        assert np.array_equal(xs[k], xb) and np.array_equal(vs[k], vb), k
+        assert np.array_equal(pe[k], pb) and np.array_equal(per[k], rb) and np.allclose(ke[k], kb, rtol=1e-13 if dtype == "float64" else 1e-6)
+    # the handle carries on from the last snapshot
+    a.step(ext)
+    b.step(ext)
+    assert np.array_equal(a.particles()[0], b.particles()[0])
+    a.close()
+    b.close()
+
+
+def test_simulate_of_the_drop_in_uses_one_read_back(oc):
+    """PIC.simulate (pic.py:175-223) on the reference's golden two-stream run: snapshot, E and PE traces of the first 60
+    steps, recorded on the device, against the reference's own per-step values."""
+    g = load_golden("g5_two_stream_N5000_Ng250")
+
+    class Fixed:
+        def reinit(self):
+            pass
+
+        def get_sample(self):
+            return g["x0_raw"].copy(), g["v0_raw"].copy()
+
+    sim = oc.PIC(N=int(g["N"]), N_mesh=int(g["Ng"]), n0=float(g["n0"]), L=float(g["L"]), dt=float(g["dt_in"]), tmin=0.0,
+                 tmax=60 * float(g["dt"]) - 1e-9, gamma=float(g["gamma"]), A=float(g["A"]), n_mode=int(g["n_mode"]), init_dist=Fixed())
+    snap, E, PE = sim.simulate(None)
+    assert snap.shape == (2 * sim.N, 61) and E.shape == PE.shape == (61,)
+    assert rel_err(E, g["H"][:61]) < 1e-10 and rel_err(PE, g["PE"][:61]) < 1e-10
+    assert np.array_equal(snap[:sim.N, 0:1], g["x_init"]) and np.array_equal(snap[sim.N:, 0:1], g["v_init"])
+    assert circ_err(snap[:sim.N, 10], g["x_10"], float(g["L"])) / float(g["L"]) < 1e-12 and rel_err(snap[sim.N:, 10], g["v_10"]) < 1e-12
+    assert np.array_equal(snap[:sim.N, 60:61], sim.x) and np.array_equal(snap[sim.N:, 60:61], sim.v)
+    sim.close()
