@@ -343,17 +343,17 @@ __device__ __forceinline__ void block_sum2(double a, double b, double* ws, doubl
 // G_{j+1/2} - G_{j-1/2} = b_j dx, so G = cumsum(b) dx - mean and E_j = -(phi_{j+1}-phi_{j-1})/(2dx)
 // = -(G_{j+1/2} + G_{j-1/2})/2; phi_{j+1} = phi_j + dx G_{j+1/2} is a second scan.
 //
-// scan_fields: ONE wave does the scans with shuffles alone (lane l owns the m = ceil(Ng / 64) consecutive nodes from
-// l m) while the other waves of the workgroup go on to the caller's barrier: no barrier inside, and the same
+// scan_fields: ONE wave (number `wave` of the workgroup) does the scans with shuffles alone (lane l owns the
+// m = ceil(Ng / 64) consecutive nodes from l m) while the other waves of the workgroup go on to the caller's barrier: no barrier inside, and the same
 // rounding whatever the size of the calling workgroup (sweep prologue, resident kernel, field_solve_kernel).
 // In: sb[0..Ng) = b = n - n0.  Out: sb = G_{j+1/2} (mean NOT removed), slot[0] = mean(G); with sp != null also
 // sp[j] = phi_j (before its mean is removed) and slot[1] = mean(phi).  The caller puts a barrier between this call
 // and any use of sb, sp or slot, and does not reuse slot before its next barrier after that.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ void scan_fields(double* __restrict__ sb, double* __restrict__ sp, int Ng, double dx,
-                                            double* __restrict__ slot) {
-  const int lane = threadIdx.x;
-  if (lane >= 64) return;
+                                            double* __restrict__ slot, int wave = 0) {
+  if ((int)(threadIdx.x >> 6) != wave) return;
+  const int lane = threadIdx.x & 63;
   const int m = (Ng + 63) / 64;
   const int lo = min(lane * m, Ng), hi = min(lo + m, Ng);
   double loc = 0.0;

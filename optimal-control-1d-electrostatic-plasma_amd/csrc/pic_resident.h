@@ -30,22 +30,48 @@ struct ResidentIO {
   double c1, c2, d1, d2;   // Yoshida-4 (integration.py:62-69): c = (c1, c2, c2, c1), d = (0, d1, d2, d1)
 };
 
-// Field tile Es (gather layout: Ng + 2 slots, OFF for TSC) from the LDS mesh `acc_all`; sb: Ng doubles of scratch.
+// What the post-step refresh of a step needs besides the meshes (pic.py:145-146): where its results go, and the LDS
+// scratch of the second scanning wave.
+struct RefreshCtx {
+  double* s2;              // Ng doubles: b = n - n0 of the refreshed density, then its G
+  double* se;              // Ng doubles: phi
+  double* slot2;           // 2 doubles
+  double* ws;              // 2 NW doubles
+  size_t row;              // env * Ng
+  int env;
+  double N_over_L;
+};
+
+// Field tile Es (gather layout: Ng + 2 slots, OFF for TSC) from the LDS mesh `acc_all`; sb: Ng doubles of scratch;
+// xt: the external field of this environment in LDS, or null.
 // While the scanning wave works, the others clear the meshes the coming particle phase deposits into (`z0`, and
 // `z1` = the mesh just read, in sub-stage D), so that the phase needs no barrier of its own for that.
-template <typename T, typename A, int SHAPE, int NW>
-__device__ __forceinline__ void resident_field(const A* __restrict__ acc_all, int R, int stride, const double* __restrict__ ext,
+//
+// kRefresh (sub-stage B of every step but the first of a launch): the post-step refresh of the PREVIOUS step -- density
+// from the mesh `z0` still holds (sub-stage D's deposit of the final positions), E, phi and the three energies -- rides
+// along: its sums go with the force field's sums, its two scans run in wave 1 next to wave 0's, its outputs with the
+// field tile; it costs no barrier of its own.  Nothing in the step that follows reads what it produces.
+template <typename T, typename A, int SHAPE, int NW, bool kRefresh>
+__device__ __forceinline__ void resident_field(const A* __restrict__ acc_all, int R, int stride, const double* __restrict__ xt,
                                                int Ng, int fg, double scale, double n0, double dx, double* __restrict__ sb,
                                                double* __restrict__ slot, T* __restrict__ Es, A* __restrict__ z0,
-                                               A* __restrict__ z1) {
+                                               A* __restrict__ z1, const ResidentIO& io, const RefreshCtx& rc, double ke_prev,
+                                               int prev_step) {
   constexpr int NT = NW * 64;
   constexpr int OFF = (SHAPE == PIC_TSC) ? 1 : 0;
   const int tid = threadIdx.x;
   const double unit = ldexp(1.0, -fg);
   for (int j = tid; j < Ng; j += NT)
     sb[j] = ((double)mesh_node_sum<A, SHAPE>(acc_all, R, stride, Ng, fg, j) * unit) * scale - n0;
-  __syncthreads();                                   // the mesh has been read: it may be cleared now
-  scan_fields(sb, nullptr, Ng, dx, slot);
+  if (kRefresh)
+    for (int j = tid; j < Ng; j += NT) {
+      const double nj = ((double)mesh_node_sum<A, SHAPE>(z0, R, stride, Ng, fg, j) * unit) * scale;
+      io.n[rc.row + j] = nj;
+      rc.s2[j] = nj - n0;
+    }
+  __syncthreads();                                   // the meshes have been read: they may be cleared now
+  scan_fields(sb, nullptr, Ng, dx, slot, 0);
+  if (kRefresh) scan_fields(rc.s2, rc.se, Ng, dx, rc.slot2, 1);
   for (int i = tid; i < R * stride; i += NT) z0[i] = A{};
   if (z1) for (int i = tid; i < R * stride; i += NT) z1[i] = A{};
   __syncthreads();
@@ -56,10 +82,44 @@ __device__ __forceinline__ void resident_field(const A* __restrict__ acc_all, in
     const double gp = sb[node] - gmean;
     const double gm = sb[node == 0 ? Ng - 1 : node - 1] - gmean;
     double E = -0.5 * (gp + gm);
-    if (ext) E += ext[node];
+    if (xt) E += xt[node];
     Es[i] = (T)E;
   }
+  if (kRefresh) {                                    // solve_block's outputs, reduction order included
+    const double g2 = rc.slot2[0], pmean = rc.slot2[1];
+    double e2 = 0.0;
+    for (int j = tid; j < Ng; j += NT) {
+      const double gp = rc.s2[j] - g2;
+      const double gm = rc.s2[j == 0 ? Ng - 1 : j - 1] - g2;
+      const double E = -0.5 * (gp + gm);
+      io.E[rc.row + j] = E;
+      e2 += E * E;
+      io.phi[rc.row + j] = rc.se[j] - pmean;
+    }
+    const double wa = wave_sum(e2), wb = wave_sum(ke_prev);
+    if ((tid & 63) == 0) {
+      rc.ws[tid >> 6] = wa;
+      rc.ws[NW + (tid >> 6)] = wb;
+    }
+  }
   __syncthreads();
+  if (kRefresh && tid == 0) {                        // ws is not written again before the next field phase's barriers
+    double S = 0.0, K = 0.0;
+    for (int i = 0; i < NW; ++i) {
+      S += rc.ws[i];
+      K += rc.ws[NW + i];
+    }
+    const double pe = 0.5 * S * dx;
+    io.PEr[rc.env] = pe;
+    io.PE[rc.env] = pe * rc.N_over_L;
+    io.KE[rc.env] = 0.5 * K;
+    if (io.hist) {
+      double* h3 = io.hist + (size_t)prev_step * 3 * io.num_envs;
+      h3[rc.env] = 0.5 * K;
+      h3[io.num_envs + rc.env] = pe * rc.N_over_L;
+      h3[2 * (size_t)io.num_envs + rc.env] = pe;
+    }
+  }
 }
 
 template <typename P, typename A, int SHAPE, int PPT, int NW, bool kCarry>
@@ -70,7 +130,7 @@ __global__ __launch_bounds__(NW * 64) void resident_kernel(typename P::X* __rest
   using X = typename P::X;
   using V = typename P::V;
 
-  // LDS: [R meshes: accA][R meshes: accB][sb: Ng doubles][se: Ng doubles][field tile Es]
+  // LDS: [R meshes: accA][R meshes: accB][sb][se][s2][xt: Ng doubles each][field tile Es]
   extern __shared__ __align__(16) unsigned char smem_raw[];
   const int Ng = a.Ng;
   const int stride = Ng + 2;
@@ -79,9 +139,11 @@ __global__ __launch_bounds__(NW * 64) void resident_kernel(typename P::X* __rest
   A* accB = accA + (size_t)R * stride;
   double* sb = reinterpret_cast<double*>(accB + (size_t)R * stride);
   double* se = sb + Ng;
-  T* Es = reinterpret_cast<T*>(se + Ng);
+  double* s2 = se + Ng;
+  double* xt_lds = s2 + Ng;
+  T* Es = reinterpret_cast<T*>(xt_lds + Ng);
   __shared__ double ws[2 * NW];
-  __shared__ double slot[2];
+  __shared__ double slot[2], slot2[2];
 
   const int tid = threadIdx.x;
   const int env = blockIdx.x;
@@ -90,8 +152,12 @@ __global__ __launch_bounds__(NW * 64) void resident_kernel(typename P::X* __rest
   const T c1 = (T)io.c1, c2 = (T)io.c2, d1 = (T)io.d1, d2 = (T)io.d2;
   X* xe = x + (size_t)env * a.ld;
   V* ve = v + (size_t)env * a.ld;
-  const double* ext = io.ext ? io.ext + (size_t)env * Ng : nullptr;
   const size_t row = (size_t)env * Ng;
+  // the external field of the force evaluations is the same for every sub-stage and step of the call: one copy in LDS
+  const double* xt = io.ext ? xt_lds : nullptr;
+  if (io.ext)
+    for (int j = tid; j < Ng; j += NT) xt_lds[j] = io.ext[row + j];
+  RefreshCtx rc{s2, se, slot2, ws, row, env, a.N_over_L};
 
   // particle tid + s NT lives in slot s of lane tid
   X xs[PPT];
@@ -135,14 +201,21 @@ __global__ __launch_bounds__(NW * 64) void resident_kernel(typename P::X* __rest
   }
   __syncthreads();
 
+  double ke = 0.0;               // sum of p^2 of this lane's particles after the step just made
   for (int step = 0; step < io.nsteps; ++step) {
-    double ke = 0.0;
+    const double ke_prev = ke;
+    ke = 0.0;
     for (int st = ST_B; st <= ST_D; ++st) {
       // sub-stage st reads the field of the deposit in `in` and deposits into `out` (D: also the next q1 into `in`)
       A* in = (st == ST_C) ? accB : accA;
       A* out = (st == ST_C) ? accA : accB;
-      resident_field<T, A, SHAPE, NW>(in, R, stride, ext, Ng, a.fg, a.scale, a.n0, a.dx, sb, slot, Es, out,
-                                      st == ST_D ? in : nullptr);
+      // (the previous step's post-step refresh goes with sub-stage B's field phase; the last step's follows the loop)
+      if (st == ST_B && step > 0)
+        resident_field<T, A, SHAPE, NW, true>(in, R, stride, xt, Ng, a.fg, a.scale, a.n0, a.dx, sb, slot, Es, out, nullptr,
+                                              io, rc, ke_prev, step - 1);
+      else
+        resident_field<T, A, SHAPE, NW, false>(in, R, stride, xt, Ng, a.fg, a.scale, a.n0, a.dx, sb, slot, Es, out,
+                                               st == ST_D ? in : nullptr, io, rc, 0.0, 0);
       // Yoshida coefficients of this sub-stage (integration.py:62-69): (c, d) = (c2, d1), (c3, d2), (c4, d3)
       const T c_cur = (st == ST_D) ? c1 : c2;
       const T d_cur = (st == ST_C) ? d2 : d1;
@@ -190,17 +263,6 @@ __global__ __launch_bounds__(NW * 64) void resident_kernel(typename P::X* __rest
       __syncthreads();
     }
 
-    // post-step refresh (pic.py:145-146; no external field: pic.py:114-117) from the deposit in accB
-    const double unit = ldexp(1.0, -a.fg);
-    for (int j = tid; j < Ng; j += NT) {
-      const double nj = ((double)mesh_node_sum<A, SHAPE>(accB, R, stride, Ng, a.fg, j) * unit) * a.scale;
-      io.n[row + j] = nj;
-      sb[j] = nj - a.n0;
-    }
-    __syncthreads();
-    SolveOut o{};
-    o.E = io.E; o.phi = io.phi; o.KE = io.KE; o.PE = io.PE; o.PEr = io.PEr;
-    solve_block<NW>(o, env, Ng, a.dx, a.N_over_L, ke, sb, se, ws, slot);
     if (io.snap) {                    // PIC.simulate's particle snapshots (pic.py:175-223), written from the registers
       using F = typename P::V;        // positions leave as floats of the particle dtype whatever their format
       F* sx = static_cast<F*>(io.snap) + ((size_t)step * 2 * io.num_envs + env) * (size_t)a.N;
@@ -216,8 +278,22 @@ __global__ __launch_bounds__(NW * 64) void resident_kernel(typename P::X* __rest
         }
       }
     }
+  }
+
+  // post-step refresh of the last step (pic.py:145-146; no external field: pic.py:114-117) from the deposit in accB
+  if (io.nsteps > 0) {
+    const double unit = ldexp(1.0, -a.fg);
+    for (int j = tid; j < Ng; j += NT) {
+      const double nj = ((double)mesh_node_sum<A, SHAPE>(accB, R, stride, Ng, a.fg, j) * unit) * a.scale;
+      io.n[row + j] = nj;
+      sb[j] = nj - a.n0;
+    }
+    __syncthreads();
+    SolveOut o{};
+    o.E = io.E; o.phi = io.phi; o.KE = io.KE; o.PE = io.PE; o.PEr = io.PEr;
+    solve_block<NW>(o, env, Ng, a.dx, a.N_over_L, ke, sb, se, ws, slot);
     if (io.hist && tid == 0) {        // this thread wrote the three energies a moment ago
-      double* h3 = io.hist + (size_t)step * 3 * io.num_envs;
+      double* h3 = io.hist + (size_t)(io.nsteps - 1) * 3 * io.num_envs;
       h3[env] = io.KE[env];
       h3[io.num_envs + env] = io.PE[env];
       h3[2 * (size_t)io.num_envs + env] = io.PEr[env];

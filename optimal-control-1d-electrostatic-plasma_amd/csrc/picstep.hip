@@ -570,13 +570,13 @@ int pic_create(const pic_config* cfg, pic_handle** out) {
     for (const auto& sh : shapes)
       if (cfg->N <= sh[2]) { h->res_nw = sh[0]; h->res_ppt = sh[1]; break; }
     h->res_R = 4;
-    auto need = [&](int R) { return (size_t)2 * R * stride * 8 + 2 * (size_t)cfg->Ng * 8 + stride * h->esz; };
+    auto need = [&](int R) { return (size_t)2 * R * stride * 8 + 4 * (size_t)cfg->Ng * 8 + stride * h->esz; };
     while (h->res_R > 1 && need(h->res_R) > 48 * 1024) h->res_R >>= 1;
     h->res_lds = need(h->res_R);
     const bool possible = h->res_nw != 0 && h->res_lds <= 64 * 1024 && h->acc_kind != PIC_ACC_F64;
     if (cfg->blocks_per_env < 0 && !possible) {
       delete h;
-      return fail(nullptr, PIC_EINVAL, "pic_create: the resident schedule needs N <= 8192, Ng <= 1600 and an integer accumulator");
+      return fail(nullptr, PIC_EINVAL, "pic_create: the resident schedule needs N <= 8192, Ng <= 1160 and an integer accumulator");
     }
     // Measured (profiles/experiments_r2.md): one workgroup steps 5000 float64 particles in ~17 us whatever the number of
     // environments, the sweeps need 22 us for one environment of 8000 and 35-110 us for 64-1024 of 5000.  A lone
