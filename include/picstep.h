@@ -225,6 +225,11 @@ int pic_own_stream(pic_handle* h);
 /* 1 if pic_step runs the resident schedule on this handle, 0 for streaming sweeps (see blocks_per_env). */
 int pic_schedule(pic_handle* h);
 
+/* Particle states of 256 MB and more: pic_create allocates several candidate blocks, streams once through each and keeps
+ * the fastest (where a block lands in HBM moves its streaming rate by up to 15 % on MI355X).  -> how many blocks were
+ * compared (1 = no comparison was made), the read+write rate of the one kept and of the slowest, in GB/s (0 if none). */
+int pic_placement_info(pic_handle* h, int* candidates, double* kept_gbytes_per_s, double* slowest_gbytes_per_s);
+
 int pic_sync(pic_handle* h);
 /* Number of particle positions found non-finite or out of range by the last sweeps (0 = healthy). */
 int pic_bad_count(pic_handle* h, int64_t* count);

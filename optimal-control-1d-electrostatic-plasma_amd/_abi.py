@@ -74,6 +74,7 @@ SIGNATURES = {
     "pic_set_stream": [_vp, _vp],
     "pic_own_stream": [_vp],
     "pic_schedule": [_vp],
+    "pic_placement_info": [_vp, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double)],
     "pic_sync": [_vp],
     "pic_bad_count": [_vp, _i64p],
     "pic_last_error": [_vp],
@@ -225,6 +226,12 @@ class Handle:
     def schedule(self):
         """'resident' (one launch per pic_step call, small environments) or 'streaming' (sweeps)."""
         return "resident" if self.lib.pic_schedule(self._h) == 1 else "streaming"
+
+    def placement_info(self):
+        """(candidate blocks pic_create compared, GB/s of the one kept, GB/s of the slowest); (1, 0, 0) for small states."""
+        n, kept, slow = C.c_int(), C.c_double(), C.c_double()
+        self._chk(self.lib.pic_placement_info(self._h, C.byref(n), C.byref(kept), C.byref(slow)))
+        return n.value, kept.value, slow.value
 
     def particles(self):
         x = np.empty((self.num_envs, self.N), dtype=self.dtype)

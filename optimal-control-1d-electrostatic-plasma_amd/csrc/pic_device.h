@@ -275,18 +275,34 @@ __device__ __forceinline__ void deposit(A* __restrict__ acc, int j, const typena
   }
 }
 
-__device__ __forceinline__ double wave_sum(double v) {
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+// Wave-level sums on the DPP path of the VALU (no LDS round trip: a ds_bpermute shuffle costs ~150 cycles per step of
+// a dependent chain, a DPP move ~10).  dpp_add<CTRL>(v) = v + (v of the lane the control selects, +0.0 where there is
+// none or the row is masked off).
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ double dpp_add(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xF, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xF, true);
+  return v + __hiloint2double(hi, lo);
+}
+
+// inclusive prefix sum over the 64 lanes: Hillis-Steele inside each row of 16 lanes (row_shr:1,2,4,8), then the row
+// totals travel on (row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3).  All 64 lanes must be active.
+__device__ __forceinline__ double wave_incl_scan(double v) {
+  v = dpp_add<0x111>(v);
+  v = dpp_add<0x112>(v);
+  v = dpp_add<0x114>(v);
+  v = dpp_add<0x118>(v);
+  v = dpp_add<0x142, 0xA>(v);
+  v = dpp_add<0x143, 0xC>(v);
   return v;
 }
 
-__device__ __forceinline__ double wave_incl_scan(double v) {
-  const int lane = threadIdx.x & 63;
-  for (int off = 1; off < 64; off <<= 1) {
-    double t = __shfl_up(v, off);
-    if (lane >= off) v += t;
-  }
-  return v;
+// sum over the 64 lanes, the same value in every lane
+__device__ __forceinline__ double wave_sum(double v) {
+  v = wave_incl_scan(v);
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+  return __hiloint2double(hi, lo);
 }
 
 // exclusive prefix of `v` over a workgroup of NW waves (ws: NW doubles of LDS); total in `total`
@@ -366,9 +382,7 @@ __device__ __forceinline__ void scan_fields(double* __restrict__ sb, double* __r
     sb[j] = g;
     loc += g;
   }
-  double tot = loc;
-  for (int off = 32; off > 0; off >>= 1) tot += __shfl_xor(tot, off);
-  const double gmean = tot / (double)Ng;
+  const double gmean = wave_sum(loc) / (double)Ng;
   if (lane == 0) slot[0] = gmean;
   if (sp) {
     loc = 0.0;
@@ -380,7 +394,7 @@ __device__ __forceinline__ void scan_fields(double* __restrict__ sb, double* __r
       ploc += run;
       run += (sb[j] - gmean) * dx;
     }
-    for (int off = 32; off > 0; off >>= 1) ploc += __shfl_xor(ploc, off);
+    ploc = wave_sum(ploc);
     if (lane == 0) slot[1] = ploc / (double)Ng;
   }
 }

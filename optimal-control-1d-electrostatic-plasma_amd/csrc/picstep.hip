@@ -81,6 +81,8 @@ struct pic_handle {
   double cs[4]{}, ds[4]{};
   hipStream_t stream = nullptr;       // the stream every call works on (own_stream, or the caller's)
   hipStream_t own_stream = nullptr;   // created by pic_create, destroyed by pic_destroy
+  int place_tried = 1;                // particle-state allocations pic_create compared (alloc_particles)
+  double place_gbs[2] = {0.0, 0.0};   // streaming rate of the one kept and of the slowest one, GB/s
   void* x = nullptr;
   void* v = nullptr;
   void* scratch = nullptr;        // [env][ld] positions of a probe (eval_field / compute_E)
@@ -472,6 +474,70 @@ int pic_abi_version(void) { return PICSTEP_ABI_VERSION; }
 
 const char* pic_last_error(pic_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
 
+// Where a large allocation lands in HBM decides how fast it streams: on MI355X the same read-modify-write kernel runs
+// at 5.25, 5.7 or 6.05 TB/s on different 1 GB hipMalloc blocks of one process, stable for the life of each block and
+// whatever the access pattern (profiles/placement_probe.hip, placement_patterns.hip; profiles/experiments_r2.md 14).
+// For particle states that live in HBM (>= 256 MB) pic_create therefore allocates candidate blocks one after the other (up to 12,
+// never more than a quarter of the free memory), streams through each, stops at the first that is clearly of the fast kind
+// and keeps the fastest it has seen; the others are freed before pic_create returns.
+hipError_t alloc_particles(pic_handle* h, size_t bytes) {
+  constexpr size_t kMinBytes = (size_t)256 << 20;
+  constexpr int kMaxCandidates = 12;
+  constexpr float kFastEnough = 1.12f;      // a block this much faster than the slowest one seen is of the fast kind: stop looking
+  hipError_t e = hipMalloc(&h->x, bytes);
+  if (e != hipSuccess || bytes < kMinBytes) return e;
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); return hipSuccess; }
+  const size_t budget = free_b / 4;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) {
+    if (e0) hipEventDestroy(e0);
+    (void)hipGetLastError();
+    return hipSuccess;
+  }
+  const long long n2 = (long long)(bytes / 2 / sizeof(double2));       // two halves, as x and v will be
+  long long nb = n2 / ((long long)BLOCK * 8);
+  if (nb < 256) nb = 256;
+  const long long chunk2 = (n2 + nb - 1) / nb;
+  auto probe = [&](void* block, float* ms) {                            // one warm pass, two timed ones
+    double2* a = static_cast<double2*>(block);
+    double2* b = a + n2;
+    bool ok = hipMemsetAsync(block, 0, bytes, h->stream) == hipSuccess;
+    hipLaunchKernelGGL(stream_probe_kernel, dim3((unsigned)nb), dim3(BLOCK), 0, h->stream, a, b, n2, chunk2, 1.0, 0);
+    ok = ok && hipEventRecord(e0, h->stream) == hipSuccess;
+    for (int r = 0; r < 2; ++r)
+      hipLaunchKernelGGL(stream_probe_kernel, dim3((unsigned)nb), dim3(BLOCK), 0, h->stream, a, b, n2, chunk2, 1.0, 0);
+    return ok && hipEventRecord(e1, h->stream) == hipSuccess && hipEventSynchronize(e1) == hipSuccess &&
+           hipEventElapsedTime(ms, e0, e1) == hipSuccess;
+  };
+  // rejected blocks stay allocated until the end, so that the allocator cannot hand the same memory out again
+  void* cand[kMaxCandidates] = {h->x};
+  float ms[kMaxCandidates];
+  int n = 0, best = 0, worst = 0;
+  bool ok = probe(cand[0], &ms[0]);
+  n = 1;
+  while (ok && n < kMaxCandidates && (size_t)n * bytes <= budget && ms[worst] < kFastEnough * ms[best]) {
+    if (hipMalloc(&cand[n], bytes) != hipSuccess) break;
+    ok = probe(cand[n], &ms[n]);
+    if (ok && ms[n] < ms[best]) best = n;
+    if (ok && ms[n] > ms[worst]) worst = n;
+    ++n;
+  }
+  hipEventDestroy(e0);
+  hipEventDestroy(e1);
+  (void)hipGetLastError();
+  if (!ok) best = 0;
+  for (int c = 0; c < n; ++c)
+    if (c != best) hipFree(cand[c]);
+  h->x = cand[best];
+  if (ok) {
+    h->place_tried = n;
+    h->place_gbs[0] = 2.0 * 2.0 * (double)bytes / (ms[best] * 1e-3) / 1e9;       // 2 passes, read + write
+    h->place_gbs[1] = 2.0 * 2.0 * (double)bytes / (ms[worst] * 1e-3) / 1e9;
+  }
+  return hipSuccess;
+}
+
 int pic_create(const pic_config* cfg, pic_handle** out) {
   if (!cfg || !out) return fail(nullptr, PIC_EINVAL, "pic_create: null argument");
   *out = nullptr;
@@ -604,7 +670,7 @@ int pic_create(const pic_config* cfg, pic_handle** out) {
   h->stream = h->own_stream;
   const size_t pbytes = (size_t)cfg->num_envs * h->ld * h->esz;
   const size_t gbytes = (size_t)cfg->num_envs * cfg->Ng * sizeof(double);
-  CREATE_CHK(hipMalloc(&h->x, 2 * pbytes));          // x and v in one allocation: [2][env][ld]
+  CREATE_CHK(alloc_particles(h, 2 * pbytes));        // x and v in one allocation: [2][env][ld]
   h->v = static_cast<char*>(h->x) + pbytes;
   CREATE_CHK(hipMemsetAsync(h->x, 0, 2 * pbytes, h->stream));
   // small states (the reference's N = 5000) are read back every step by a Gym-style loop: one copy of x and v
@@ -676,6 +742,14 @@ int pic_own_stream(pic_handle* h) {
 }
 
 int pic_schedule(pic_handle* h) { return h ? (h->resident ? 1 : 0) : PIC_EINVAL; }
+
+int pic_placement_info(pic_handle* h, int* candidates, double* kept_gbytes_per_s, double* slowest_gbytes_per_s) {
+  if (!h) return PIC_EINVAL;
+  if (candidates) *candidates = h->place_tried;
+  if (kept_gbytes_per_s) *kept_gbytes_per_s = h->place_gbs[0];
+  if (slowest_gbytes_per_s) *slowest_gbytes_per_s = h->place_gbs[1];
+  return PIC_OK;
+}
 
 int pic_sync(pic_handle* h) {
   if (!h) return PIC_EINVAL;
