@@ -117,8 +117,8 @@ def cpu_baseline(N, Ng, L, dt, budget_s=20.0, procs=1):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--envs", type=int, default=64, help="environments per GPU")
     ap.add_argument("--particles", type=int, default=1_000_000)
     ap.add_argument("--mesh", type=int, default=256)

@@ -10,10 +10,10 @@ OUT=$ROOT/gpurun_out
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 # 1. unprofiled bench line (with the 1-core CPU baseline leg)
-python3 $ROOT/bench.py --steps 20 --warmup 3 > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err || exit 1
+python3 $ROOT/bench.py > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err || exit 1
 echo "bench done"
 # 2. kernel trace + stats of the same command (its own JSON line is kept: the profiled process runs slower)
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_kt -o kt -- python3 $ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline \
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_kt -o kt -- python3 $ROOT/bench.py --no-cpu-baseline \
   > $OUT/${TAG}_bench_under_rocprofv3.json 2> $OUT/${TAG}_kt.err || exit 1
 echo "kernel trace done"
 # 3. HBM traffic: one counter per pass, nothing else enabled
@@ -39,5 +39,5 @@ cp profiles/${TAG}_kernel_stats.csv profiles/${TAG}_summary.json profiles/${TAG}
 python3 profiles/regimes.py $OUT/${TAG}_regimes > $OUT/${TAG}_regimes.md 2> $OUT/${TAG}_regimes.err
 # 6. CPU comparators of SURVEY 8d: (a) one core at config 1, (b) one process per core at config 2
 python3 bench.py --steps 200 --warmup 20 --envs 1 --particles 10000 --mesh 128 > $OUT/${TAG}_bench_config1.json 2> /dev/null
-python3 bench.py --steps 20 --warmup 3 --cpu-procs 16 > $OUT/${TAG}_bench_cpu16.json 2> /dev/null
+python3 bench.py --cpu-procs 16 > $OUT/${TAG}_bench_cpu16.json 2> /dev/null
 ls -la $OUT | tail -30
