@@ -55,6 +55,8 @@ int main(int argc, char** argv) {
       {"one hipMalloc, v starts 2 MiB-aligned after x", 2 * arr + (4u << 20), false, ((arr + (2u << 20) - 1) / (2u << 20)) * (2u << 20) - arr},
       {"one hipMalloc, size rounded up to a multiple of 2 MiB", (2 * arr + (2u << 20) - 1) / (2u << 20) * (2u << 20), false, 0},
       {"one hipMalloc of 1,024,000,000 B, a 12,345,678 B allocation in front of each", 2 * arr, false, 0},
+      {"hipExtMallocWithFlags(hipDeviceMallocContiguous), 1,024,000,000 B", 2 * arr, false, 0},
+      {"hipExtMallocWithFlags(hipDeviceMallocUncached), 1,024,000,000 B", 2 * arr, false, 0},
   };
   int mi = -1;
   for (const Mode& m : modes) {
@@ -64,7 +66,11 @@ int main(int argc, char** argv) {
     std::vector<void*> owned;
     for (int k = 0; k < K; ++k) {
       if (mi == 5) { void* junk; CHK(hipMalloc(&junk, 12345678)); owned.push_back(junk); }
-      void* p; CHK(hipMalloc(&p, m.alloc)); CHK(hipMemset(p, 0, m.alloc)); owned.push_back(p);
+      void* p;
+      if (mi == 6) CHK(hipExtMallocWithFlags(&p, m.alloc, hipDeviceMallocContiguous));
+      else if (mi == 7) CHK(hipExtMallocWithFlags(&p, m.alloc, hipDeviceMallocUncached));
+      else CHK(hipMalloc(&p, m.alloc));
+      CHK(hipMemset(p, 0, m.alloc)); owned.push_back(p);
       double2* a = static_cast<double2*>(p);
       double2* b;
       if (m.apart) { void* q; CHK(hipMalloc(&q, m.alloc)); CHK(hipMemset(q, 0, m.alloc)); owned.push_back(q); b = static_cast<double2*>(q); }
