@@ -57,17 +57,23 @@ float run(int envs, int nblk, long long n2_env, int reps, int lds, double2* a, d
 }
 
 int main(int argc, char** argv) {
-  int envs = 64, reps = 10;
+  int envs = 64, reps = 10, contiguous = 0;
   long long N = 1000000;
   for (int i = 1; i < argc; ++i) {
     if (!strcmp(argv[i], "--envs")) envs = atoi(argv[++i]);
     else if (!strcmp(argv[i], "--particles")) N = atoll(argv[++i]);
     else if (!strcmp(argv[i], "--reps")) reps = atoi(argv[++i]);
+    else if (!strcmp(argv[i], "--contiguous")) contiguous = 1;   // one physically contiguous block (always of the slow kind)
   }
   const long long n2_env = N / 2;
   const size_t bytes = (size_t)envs * n2_env * 16;
   double2 *a, *b;
-  CHK(hipMalloc(&a, bytes)); CHK(hipMalloc(&b, bytes));
+  if (contiguous) {
+    void* p; CHK(hipExtMallocWithFlags(&p, 2 * bytes, hipDeviceMallocContiguous));
+    a = static_cast<double2*>(p); b = a + bytes / 16;
+  } else {
+    CHK(hipMalloc(&a, bytes)); CHK(hipMalloc(&b, bytes));
+  }
   CHK(hipMemset(a, 0, bytes)); CHK(hipMemset(b, 0, bytes));
   const double gb = 4.0 * bytes / 1e9;
   printf("envs=%d N=%lld: %.3f GB read+written per launch\n", envs, N, gb);
