@@ -477,12 +477,12 @@ const char* pic_last_error(pic_handle* h) { return h ? h->err.c_str() : g_create
 // Where a large allocation lands in HBM decides how fast it streams: on MI355X the same read-modify-write kernel runs
 // at 5.25, 5.7 or 6.05 TB/s on different 1 GB hipMalloc blocks of one process, stable for the life of each block and
 // whatever the access pattern (profiles/placement_probe.hip, placement_patterns.hip; profiles/experiments_r2.md 14).
-// For particle states that live in HBM (>= 256 MB) pic_create therefore allocates candidate blocks one after the other (up to 12,
+// For particle states that live in HBM (>= 256 MB) pic_create therefore allocates candidate blocks one after the other (up to 48,
 // never more than a quarter of the free memory), streams through each, stops at the first that is clearly of the fast kind
 // and keeps the fastest it has seen; the others are freed before pic_create returns.
 hipError_t alloc_particles(pic_handle* h, size_t bytes) {
   constexpr size_t kMinBytes = (size_t)256 << 20;
-  constexpr int kMaxCandidates = 12;
+  constexpr int kMaxCandidates = 48;        // fast blocks are rare on a box whose memory is unfragmented: about one per 24 GB (experiments_r2.md 15)
   constexpr float kFastEnough = 1.12f;      // a block this much faster than the slowest one seen is of the fast kind: stop looking
   hipError_t e = hipMalloc(&h->x, bytes);
   if (e != hipSuccess || bytes < kMinBytes) return e;

@@ -29,6 +29,12 @@ __global__ __launch_bounds__(BLOCK) void stream(double2* __restrict__ a, double2
   double2* ae = a + (size_t)env * n2_env;
   double2* be = b + (size_t)env * n2_env;
   const long long ntiles = (n2_env + BLOCK - 1) / BLOCK;
+  if (MODE == 5) {   // chunks dealt to the workgroups by a fixed permutation over the whole buffer: the resident set is spread over all pages
+    const unsigned lin = blockIdx.x + gridDim.x * blockIdx.y, W = gridDim.x * gridDim.y;
+    const unsigned l2 = (unsigned)(((unsigned long long)lin * 2654435761ull) % W);   // a bijection when W is not a multiple of the prime factors of the constant
+    env = l2 / gridDim.x; blk = l2 % gridDim.x;
+    ae = a + (size_t)env * n2_env; be = b + (size_t)env * n2_env;
+  }
   for (int k = 0; k < tiles_per_chunk; ++k) {
     long long t;
     if (MODE == 1) t = (long long)k * nblk + blk;
@@ -67,7 +73,10 @@ int main(int argc, char** argv) {
   const size_t arr = (size_t)envs * n2_env * 16;
   std::vector<double2*> A, B;
   for (int k = 0; k < K; ++k) {
-    void* p; CHK(hipMalloc(&p, 2 * arr)); CHK(hipMemset(p, 0, 2 * arr));
+    void* p;
+    if (argc > 2) CHK(hipExtMallocWithFlags(&p, 2 * arr, hipDeviceMallocContiguous));   // physically contiguous: always of the slow kind
+    else CHK(hipMalloc(&p, 2 * arr));
+    CHK(hipMemset(p, 0, 2 * arr));
     A.push_back(static_cast<double2*>(p));
     B.push_back(reinterpret_cast<double2*>(static_cast<char*>(p) + arr));
   }
@@ -77,7 +86,9 @@ int main(int argc, char** argv) {
                     {"P6 transposed grid (8)    ", 3, 8}, {"P7 transposed grid (9)    ", 3, 9}, {"P8 chunks of 4 tiles      ", 0, 4},
                     {"P9 chunks of 16 tiles     ", 0, 16}, {"P10 chunks of 13 tiles    ", 0, 13}, {"P11 cyclic tiles (4 each) ", 1, 4},
                     {"P12 XCD-aware, 8 tiles    ", 4, 8}, {"P13 XCD-aware, 4 tiles    ", 4, 4}, {"P14 XCD-aware, 16 tiles   ", 4, 16},
-                    {"P15 chunks of 2 tiles     ", 0, 2}, {"P16 XCD-aware, 2 tiles    ", 4, 2}};
+                    {"P15 chunks of 2 tiles     ", 0, 2}, {"P16 XCD-aware, 2 tiles    ", 4, 2},
+                    {"P17 permuted chunks, 8    ", 5, 8}, {"P18 permuted chunks, 4    ", 5, 4}, {"P19 permuted chunks, 2    ", 5, 2},
+                    {"P20 permuted chunks, 1    ", 5, 1}, {"P21 permuted chunks, 16   ", 5, 16}};
   for (int round = 0; round < 2; ++round)
     for (const P& p : pats) {
       printf("%s:", p.name);
@@ -85,7 +96,7 @@ int main(int argc, char** argv) {
       for (int k = 0; k < K; ++k) {
         float t = p.mode == 0 ? run<0>(A[k], B[k], envs, n2_env, p.tpc, 5) : p.mode == 1 ? run<1>(A[k], B[k], envs, n2_env, p.tpc, 5)
                 : p.mode == 2 ? run<2>(A[k], B[k], envs, n2_env, p.tpc, 5) : p.mode == 3 ? run<3>(A[k], B[k], envs, n2_env, p.tpc, 5)
-                : run<4>(A[k], B[k], envs, n2_env, p.tpc, 5);
+                : p.mode == 4 ? run<4>(A[k], B[k], envs, n2_env, p.tpc, 5) : run<5>(A[k], B[k], envs, n2_env, p.tpc, 5);
         printf(" %6.1f", t); sum += t; mx = t > mx ? t : mx;
       }
       printf("   mean %6.1f max %6.1f us\n", sum / K, mx);

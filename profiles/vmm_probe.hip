@@ -47,7 +47,7 @@ float run(double2* a, double2* b, int envs, long long n2_env, int reps) {
 }
 
 struct Mapped {
-  void* va = nullptr; size_t size = 0;
+  void* va = nullptr; size_t size = 0; size_t G = 0;
   std::vector<hipMemGenericAllocationHandle_t> all;
 };
 
@@ -58,7 +58,7 @@ Mapped build(size_t bytes, size_t G, int mode, int stride, int dev) {
   prop.location.type = hipMemLocationTypeDevice;
   prop.location.id = dev;
   const size_t n = (bytes + G - 1) / G;
-  m.size = n * G;
+  m.size = n * G; m.G = G;
   const size_t total = n * (size_t)stride;
   m.all.resize(total);
   for (size_t i = 0; i < total; ++i) CHK(hipMemCreate(&m.all[i], G, &prop, 0));
@@ -84,12 +84,13 @@ Mapped build(size_t bytes, size_t G, int mode, int stride, int dev) {
 
 void destroy(Mapped& m) {
   CHK(hipDeviceSynchronize());
-  CHK(hipMemUnmap(m.va, m.size));
+  for (size_t off = 0; off < m.size; off += m.G) CHK(hipMemUnmap(static_cast<char*>(m.va) + off, m.G));
   for (auto h : m.all) CHK(hipMemRelease(h));
   CHK(hipMemAddressFree(m.va, m.size));
 }
 
-int main() {
+int main(int argc, char** argv) {
+  const bool together = argc > 1;
   const int envs = 64; const long long n2_env = 500000; const size_t arr = (size_t)envs * n2_env * 16;
   hipMemAllocationProp prop{};
   prop.type = hipMemAllocationTypePinned; prop.location.type = hipMemLocationTypeDevice; prop.location.id = 0;
@@ -117,7 +118,7 @@ int main() {
     destroy(m);
   }
   // several mapped ranges and several plain blocks alive at once
-  {
+  if (together) {
     std::vector<Mapped> ms; std::vector<void*> ps;
     for (int k = 0; k < 6; ++k) {
       ms.push_back(build(2 * arr, k % 2 ? (size_t)2 << 20 : (size_t)1 << 30, 0, 1, 0));
