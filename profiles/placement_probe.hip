@@ -43,7 +43,8 @@ float run(double2* a, double2* b, int envs, long long n2_env, int reps) {
 }
 
 int main(int argc, char** argv) {
-  const int envs = 64, K = argc > 1 ? atoi(argv[1]) : 8;
+  const int K = argc > 1 ? atoi(argv[1]) : 8;
+  const int envs = argc > 3 ? atoi(argv[3]) : 64;          // 12: the state fits the 256 MB Infinity Cache
   const int only = argc > 2 ? atoi(argv[2]) : -1;      // run just this allocation style (fresh process per style)
   const long long N = 1000000, n2_env = N / 2;
   const size_t arr = (size_t)envs * n2_env * 16;          // one array: 512,000,000 B
@@ -80,7 +81,7 @@ int main(int argc, char** argv) {
     printf("%s\n", m.name);
     for (int round = 0; round < 3; ++round) {
       printf("  round %d:", round);
-      for (int k = 0; k < K; ++k) printf(" %6.1f", run(A[k], B[k], envs, n2_env, 5));
+      for (int k = 0; k < K; ++k) printf(" %6.1f", run(A[k], B[k], envs, n2_env, envs < 32 ? 20 : 5));
       printf(" us\n");
     }
     for (void* p : owned) CHK(hipFree(p));
