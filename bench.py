@@ -306,8 +306,9 @@ def main():
         "algorithmic_frac_of_step": value / world * ALGORITHMIC_BYTES_PER_PARTICLE_STEP[args.dtype] / (HBM_PEAK_GBS * 1e9),
         "per_rank_ms_per_step": per_rank_ms, "returns_all_gather_ms": gather_ms,
         "energy_drift": drift, "bad_positions": bad, "mean_return": float(returns.mean().item()),
-        # pic_create's choice among candidate blocks for the particle state: (blocks compared, GB/s kept, GB/s slowest)
-        "placement": dict(zip(("candidates", "kept_GBs", "slowest_GBs"), env._h.placement_info())),
+        # pic_create's search for two different HBM regions for x and v: (x, v) placements timed, bare-stream GB/s of the pair
+        # kept and of the slowest pair seen
+        "placement": dict(zip(("pairs_timed", "kept_GBs", "slowest_GBs"), env._h.placement_info())),
         "roofline": roof, "kernels": kernels,
     }
     if rank == 0:

@@ -228,7 +228,7 @@ class Handle:
         return "resident" if self.lib.pic_schedule(self._h) == 1 else "streaming"
 
     def placement_info(self):
-        """(candidate blocks pic_create compared, GB/s of the one kept, GB/s of the slowest); (1, 0, 0) for small states."""
+        """((x, v) placements pic_create timed, GB/s of the pair kept, GB/s of the slowest pair); (1, 0, 0) for small states."""
         n, kept, slow = C.c_int(), C.c_double(), C.c_double()
         self._chk(self.lib.pic_placement_info(self._h, C.byref(n), C.byref(kept), C.byref(slow)))
         return n.value, kept.value, slow.value

@@ -81,7 +81,8 @@ struct pic_handle {
   double cs[4]{}, ds[4]{};
   hipStream_t stream = nullptr;       // the stream every call works on (own_stream, or the caller's)
   hipStream_t own_stream = nullptr;   // created by pic_create, destroyed by pic_destroy
-  int place_tried = 1;                // particle-state allocations pic_create compared (alloc_particles)
+  bool v_separate = false;            // v is an allocation of its own (large states: alloc_particles)
+  int place_tried = 1;                // (x, v) placements pic_create timed (alloc_particles)
   double place_gbs[2] = {0.0, 0.0};   // streaming rate of the one kept and of the slowest one, GB/s
   void* x = nullptr;
   void* v = nullptr;
@@ -474,66 +475,88 @@ int pic_abi_version(void) { return PICSTEP_ABI_VERSION; }
 
 const char* pic_last_error(pic_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
 
-// Where a large allocation lands in HBM decides how fast it streams: on MI355X the same read-modify-write kernel runs
-// at 5.25, 5.7 or 6.05 TB/s on different 1 GB hipMalloc blocks of one process, stable for the life of each block and
-// whatever the access pattern (profiles/placement_probe.hip, placement_patterns.hip; profiles/experiments_r2.md 14).
-// For particle states that live in HBM (>= 256 MB) pic_create therefore allocates candidate blocks one after the other (up to 48,
-// never more than a quarter of the free memory), streams through each, stops at the first that is clearly of the fast kind
-// and keeps the fastest it has seen; the others are freed before pic_create returns.
-hipError_t alloc_particles(pic_handle* h, size_t bytes) {
+// Where x and v land in HBM decides how fast they stream together.  MI355X's 288 GiB are nine regions of 32 GiB; a kernel
+// that streams two arrays lying in the SAME region runs at 5.25 TB/s, with the arrays in two DIFFERENT regions at
+// 6.05 TB/s, whichever regions and whatever the access pattern (profiles/window_probe.hip: one 120 GiB block, x fixed,
+// v moved through it; profiles/experiments_r2.md 15).  A fresh device hands out neighbouring memory, so x and v of a
+// default allocation share a region almost always.
+// For particle states that live in HBM (>= 256 MB) x and v are therefore two allocations: x first, then blocks of the same
+// size one after the other (they are laid down in sequence, 32 GiB is at most 64 blocks of config 2); every few blocks the
+// pair (x, block) is timed with a streaming pass, the first pair of the fast kind wins, everything else is freed
+// before pic_create returns.  Never more than a quarter of the free memory is held.  Smaller states keep x | v in one block
+// (they sit in the Infinity Cache, and the one-copy read-back of pic_get_particles wants them adjacent).
+hipError_t alloc_particles(pic_handle* h, size_t pbytes) {
   constexpr size_t kMinBytes = (size_t)256 << 20;
-  constexpr int kMaxCandidates = 48;        // fast blocks are rare on a box whose memory is unfragmented: about one per 24 GB (experiments_r2.md 15)
-  constexpr float kFastEnough = 1.12f;      // a block this much faster than the slowest one seen is of the fast kind: stop looking
-  hipError_t e = hipMalloc(&h->x, bytes);
-  if (e != hipSuccess || bytes < kMinBytes) return e;
-  size_t free_b = 0, total_b = 0;
-  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); return hipSuccess; }
-  const size_t budget = free_b / 4;
-  hipEvent_t e0 = nullptr, e1 = nullptr;
-  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) {
-    if (e0) hipEventDestroy(e0);
-    (void)hipGetLastError();
-    return hipSuccess;
+  constexpr size_t kStride = (size_t)3 << 30;       // memory laid down between two timed candidates (a region is 32 GiB)
+  constexpr double kFastGBs = 5880.0;               // streaming rate of a pair of the fast kind (slow 5000-5300, in between 5400-5800, fast 5900-6050)
+  constexpr int kMaxBlocks = 160;
+  if (2 * pbytes < kMinBytes) {
+    const hipError_t e = hipMalloc(&h->x, 2 * pbytes);
+    h->v = static_cast<char*>(h->x) + pbytes;
+    return e;
   }
-  const long long n2 = (long long)(bytes / 2 / sizeof(double2));       // two halves, as x and v will be
+  hipError_t e = hipMalloc(&h->x, pbytes);
+  if (e != hipSuccess) return e;
+  h->v_separate = true;
+  size_t free_b = 0, total_b = 0;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  bool ok = hipMemGetInfo(&free_b, &total_b) == hipSuccess && hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess;
+  const size_t budget = free_b / 4;
+  const long long n2 = (long long)(pbytes / sizeof(double2));
   long long nb = n2 / ((long long)BLOCK * 8);
   if (nb < 256) nb = 256;
   const long long chunk2 = (n2 + nb - 1) / nb;
-  auto probe = [&](void* block, float* ms) {                            // one warm pass, two timed ones
-    double2* a = static_cast<double2*>(block);
-    double2* b = a + n2;
-    bool ok = hipMemsetAsync(block, 0, bytes, h->stream) == hipSuccess;
+  auto pair_ms = [&](void* vb, float* ms) {                            // one warm pass, two timed ones over x and the candidate
+    double2* a = static_cast<double2*>(h->x);
+    double2* b = static_cast<double2*>(vb);
+    bool good = hipMemsetAsync(vb, 0, pbytes, h->stream) == hipSuccess;
     hipLaunchKernelGGL(stream_probe_kernel, dim3((unsigned)nb), dim3(BLOCK), 0, h->stream, a, b, n2, chunk2, 1.0, 0);
-    ok = ok && hipEventRecord(e0, h->stream) == hipSuccess;
+    good = good && hipEventRecord(e0, h->stream) == hipSuccess;
     for (int r = 0; r < 2; ++r)
       hipLaunchKernelGGL(stream_probe_kernel, dim3((unsigned)nb), dim3(BLOCK), 0, h->stream, a, b, n2, chunk2, 1.0, 0);
-    return ok && hipEventRecord(e1, h->stream) == hipSuccess && hipEventSynchronize(e1) == hipSuccess &&
+    return good && hipEventRecord(e1, h->stream) == hipSuccess && hipEventSynchronize(e1) == hipSuccess &&
            hipEventElapsedTime(ms, e0, e1) == hipSuccess;
   };
-  // rejected blocks stay allocated until the end, so that the allocator cannot hand the same memory out again
-  void* cand[kMaxCandidates] = {h->x};
-  float ms[kMaxCandidates];
-  int n = 0, best = 0, worst = 0;
-  bool ok = probe(cand[0], &ms[0]);
-  n = 1;
-  while (ok && n < kMaxCandidates && (size_t)n * bytes <= budget && ms[worst] < kFastEnough * ms[best]) {
-    if (hipMalloc(&cand[n], bytes) != hipSuccess) break;
-    ok = probe(cand[n], &ms[n]);
-    if (ok && ms[n] < ms[best]) best = n;
-    if (ok && ms[n] > ms[worst]) worst = n;
-    ++n;
+  const double gb_per_ms = 2.0 * 4.0 * (double)pbytes / 1e6;          // 2 passes, 2 arrays read and written: GB/s = this / ms
+  std::vector<void*> blocks;                                          // every block taken after x, in order
+  void* best = nullptr;
+  float best_ms = 0.f, worst_ms = 0.f;
+  int timed = 0;
+  size_t since_timed = kStride;                                       // the first block is timed
+  if (ok) ok = hipMemsetAsync(h->x, 0, pbytes, h->stream) == hipSuccess;
+  while (ok && (int)blocks.size() < kMaxBlocks && (blocks.size() + 2) * pbytes <= budget) {
+    void* b = nullptr;
+    if (hipMalloc(&b, pbytes) != hipSuccess) break;
+    blocks.push_back(b);
+    since_timed += pbytes;
+    if (since_timed < kStride && blocks.size() > 3) continue;         // (the first blocks are all timed: recycled memory often pairs at once)
+    since_timed = 0;
+    float ms = 0.f;
+    ok = pair_ms(b, &ms);
+    if (!ok) break;
+    ++timed;
+    if (!best || ms < best_ms) { best = b; best_ms = ms; }
+    if (ms > worst_ms) worst_ms = ms;
+    if (gb_per_ms / best_ms >= kFastGBs) break;
   }
-  hipEventDestroy(e0);
-  hipEventDestroy(e1);
+  if (e0) hipEventDestroy(e0);
+  if (e1) hipEventDestroy(e1);
   (void)hipGetLastError();
-  if (!ok) best = 0;
-  for (int c = 0; c < n; ++c)
-    if (c != best) hipFree(cand[c]);
-  h->x = cand[best];
-  if (ok) {
-    h->place_tried = n;
-    h->place_gbs[0] = 2.0 * 2.0 * (double)bytes / (ms[best] * 1e-3) / 1e9;       // 2 passes, read + write
-    h->place_gbs[1] = 2.0 * 2.0 * (double)bytes / (ms[worst] * 1e-3) / 1e9;
+  if (!best) {                                                        // nothing could be timed: any block will do
+    if (blocks.empty()) {
+      e = hipMalloc(&best, pbytes);
+      if (e != hipSuccess) return e;
+    } else {
+      best = blocks.front();
+    }
+  }
+  for (void* b : blocks)
+    if (b != best) hipFree(b);
+  h->v = best;
+  h->place_tried = timed > 0 ? timed : 1;
+  if (timed > 0) {
+    h->place_gbs[0] = gb_per_ms / best_ms;
+    h->place_gbs[1] = gb_per_ms / worst_ms;
   }
   return hipSuccess;
 }
@@ -670,9 +693,9 @@ int pic_create(const pic_config* cfg, pic_handle** out) {
   h->stream = h->own_stream;
   const size_t pbytes = (size_t)cfg->num_envs * h->ld * h->esz;
   const size_t gbytes = (size_t)cfg->num_envs * cfg->Ng * sizeof(double);
-  CREATE_CHK(alloc_particles(h, 2 * pbytes));        // x and v in one allocation: [2][env][ld]
-  h->v = static_cast<char*>(h->x) + pbytes;
-  CREATE_CHK(hipMemsetAsync(h->x, 0, 2 * pbytes, h->stream));
+  CREATE_CHK(alloc_particles(h, pbytes));            // x, v: [env][ld] each
+  CREATE_CHK(hipMemsetAsync(h->x, 0, pbytes, h->stream));
+  CREATE_CHK(hipMemsetAsync(h->v, 0, pbytes, h->stream));
   // small states (the reference's N = 5000) are read back every step by a Gym-style loop: one copy of x and v
   // together into pinned memory instead of two copies into pageable memory
   if (2 * (size_t)cfg->num_envs * cfg->N * h->esz <= ((size_t)4 << 20))
@@ -716,6 +739,7 @@ int pic_destroy(pic_handle* h) {
                   h->basis, h->act, h->modes, h->aux_n, h->aux_E, h->aux_pe, h->aux_phi, h->KE, h->bad};
   for (void* b : bufs)
     if (b) hipFree(b);
+  if (h->v_separate && h->v) hipFree(h->v);
   if (h->h_scal) hipHostFree(h->h_scal);
   if (h->h_part) hipHostFree(h->h_part);
   if (h->own_stream) hipStreamDestroy(h->own_stream);
