@@ -17,6 +17,31 @@ __global__ __launch_bounds__(BLOCK) void stream(double2* __restrict__ a, double2
     ae[i] = u; be[i] = w;
   }
 }
+// the same stream with the environments in G groups, each group's x and v at their own addresses
+struct Bases { double2* a[8]; double2* b[8]; int per; };
+__global__ __launch_bounds__(BLOCK) void stream_groups(Bases bs, long long n2_env, long long chunk2) {
+  const int env = blockIdx.y, blk = blockIdx.x, g = env / bs.per, e = env % bs.per;
+  const long long begin = (long long)blk * chunk2;
+  const long long end = begin + chunk2 < n2_env ? begin + chunk2 : n2_env;
+  double2* ae = bs.a[g] + (size_t)e * n2_env; double2* be = bs.b[g] + (size_t)e * n2_env;
+  for (long long i = begin + threadIdx.x; i < end; i += BLOCK) {
+    double2 u = ae[i], w = be[i];
+    u.x += w.x; u.y += w.y; w.x += 1.0; w.y += 1.0;
+    ae[i] = u; be[i] = w;
+  }
+}
+float run_groups(const Bases& bs) {
+  const int envs = 64, nblk = 123, reps = 4; const long long n2_env = 500000;
+  const long long chunk2 = ((n2_env + nblk - 1) / nblk + BLOCK - 1) / BLOCK * BLOCK;
+  dim3 grid((unsigned)((n2_env + chunk2 - 1) / chunk2), envs);
+  hipEvent_t e0, e1; CHK(hipEventCreate(&e0)); CHK(hipEventCreate(&e1));
+  hipLaunchKernelGGL(stream_groups, grid, dim3(BLOCK), 0, 0, bs, n2_env, chunk2);
+  CHK(hipEventRecord(e0, 0));
+  for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(stream_groups, grid, dim3(BLOCK), 0, 0, bs, n2_env, chunk2);
+  CHK(hipEventRecord(e1, 0)); CHK(hipEventSynchronize(e1)); CHK(hipGetLastError());
+  float ms = 0; CHK(hipEventElapsedTime(&ms, e0, e1)); (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  return ms / reps * 1e3f;
+}
 float run(double2* a, double2* b) {
   const int envs = 64, nblk = 123, reps = 4; const long long n2_env = 500000;
   const long long chunk2 = ((n2_env + nblk - 1) / nblk + BLOCK - 1) / BLOCK * BLOCK;
@@ -52,6 +77,24 @@ int main(int argc, char** argv) {
       printf("  D=%g: %.0f", D, run((double2*)(base + w), (double2*)(base + w + d)));
     }
     printf("\n");
+  }
+  // environments in G groups; group g's x at (1 + xs g) GiB, its v at (1 + vo + vs g) GiB
+  struct Lay { const char* name; int G; double xs, vo, vs; };
+  const Lay lays[] = {{"1 group, x and v in one region", 1, 0, 0.4768, 0}, {"1 group, v one region further", 1, 0, 33, 0},
+                      {"2 groups: x in regions 0,1, v in 2,3", 2, 32, 64, 32}, {"2 groups: x in regions 0,1, v in 1,0 (crossed)", 2, 32, 32.5, -32},
+                      {"2 groups: x in 0,0, v in 1,1", 2, 0.25, 33, 0.25}, {"3 groups (22 envs): x in 0,1,2 v in 1,2,3", 3, 32, 32.5, 32},
+                      {"8 groups: x in 0, v spread over 1,1,2,2,3,3,1,2", 8, 0.06, 33, 8}};
+  for (const Lay& l : lays) {
+    Bases bs{}; bs.per = (64 + l.G - 1) / l.G;
+    bool fits = true;
+    for (int g = 0; g < l.G; ++g) {
+      const double xg = 1.0 + l.xs * g, vg = 1.0 + l.vo + l.vs * g;
+      const size_t xo = (size_t)(xg * 1024.0) << 20, vo = (size_t)(vg * 1024.0) << 20;
+      if (xo + arr > total || vo + arr > total || vg < 0) fits = false;
+      bs.a[g] = (double2*)(base + xo); bs.b[g] = (double2*)(base + vo);
+    }
+    if (!fits) { printf("%s: does not fit\n", l.name); continue; }
+    printf("%-52s: %.0f %.0f us\n", l.name, run_groups(bs), run_groups(bs));
   }
   return 0;
 }
