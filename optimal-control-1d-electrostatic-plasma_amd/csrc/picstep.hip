@@ -483,13 +483,13 @@ const char* pic_last_error(pic_handle* h) { return h ? h->err.c_str() : g_create
 // For particle states that live in HBM (>= 256 MB) x and v are therefore two allocations: x first, then blocks of the same
 // size one after the other (they are laid down in sequence, 32 GiB is at most 64 blocks of config 2); every few blocks the
 // pair (x, block) is timed with a streaming pass, the first pair of the fast kind wins, everything else is freed
-// before pic_create returns.  Never more than a quarter of the free memory is held.  Smaller states keep x | v in one block
+// before pic_create returns.  Never more than a third of the free memory is held (the partner region can be 64 GiB away).  Smaller states keep x | v in one block
 // (they sit in the Infinity Cache, and the one-copy read-back of pic_get_particles wants them adjacent).
 hipError_t alloc_particles(pic_handle* h, size_t pbytes) {
   constexpr size_t kMinBytes = (size_t)256 << 20;
   constexpr size_t kStride = (size_t)3 << 30;       // memory laid down between two timed candidates (a region is 32 GiB)
   constexpr double kFastGBs = 5880.0;               // streaming rate of a pair of the fast kind (slow 5000-5300, in between 5400-5800, fast 5900-6050)
-  constexpr int kMaxBlocks = 160;
+  constexpr int kMaxBlocks = 192;
   if (2 * pbytes < kMinBytes) {
     const hipError_t e = hipMalloc(&h->x, 2 * pbytes);
     h->v = static_cast<char*>(h->x) + pbytes;
@@ -501,7 +501,7 @@ hipError_t alloc_particles(pic_handle* h, size_t pbytes) {
   size_t free_b = 0, total_b = 0;
   hipEvent_t e0 = nullptr, e1 = nullptr;
   bool ok = hipMemGetInfo(&free_b, &total_b) == hipSuccess && hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess;
-  const size_t budget = free_b / 4;
+  const size_t budget = free_b / 3;
   const long long n2 = (long long)(pbytes / sizeof(double2));
   long long nb = n2 / ((long long)BLOCK * 8);
   if (nb < 256) nb = 256;

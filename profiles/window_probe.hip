@@ -42,6 +42,31 @@ float run_groups(const Bases& bs) {
   float ms = 0; CHK(hipEventElapsedTime(&ms, e0, e1)); (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
   return ms / reps * 1e3f;
 }
+// out of place: read a, b; write c, d
+__global__ __launch_bounds__(BLOCK) void stream_oop(const double2* __restrict__ a, const double2* __restrict__ b, double2* __restrict__ c,
+                                                    double2* __restrict__ d, long long n2_env, long long chunk2) {
+  const int env = blockIdx.y, blk = blockIdx.x;
+  const long long begin = (long long)blk * chunk2;
+  const long long end = begin + chunk2 < n2_env ? begin + chunk2 : n2_env;
+  const size_t o = (size_t)env * n2_env;
+  for (long long i = begin + threadIdx.x; i < end; i += BLOCK) {
+    double2 u = a[o + i], w = b[o + i];
+    u.x += w.x; u.y += w.y; w.x += 1.0; w.y += 1.0;
+    c[o + i] = u; d[o + i] = w;
+  }
+}
+float run_oop(double2* a, double2* b, double2* c, double2* d) {
+  const int envs = 64, nblk = 123, reps = 4; const long long n2_env = 500000;
+  const long long chunk2 = ((n2_env + nblk - 1) / nblk + BLOCK - 1) / BLOCK * BLOCK;
+  dim3 grid((unsigned)((n2_env + chunk2 - 1) / chunk2), envs);
+  hipEvent_t e0, e1; CHK(hipEventCreate(&e0)); CHK(hipEventCreate(&e1));
+  hipLaunchKernelGGL(stream_oop, grid, dim3(BLOCK), 0, 0, a, b, c, d, n2_env, chunk2);
+  CHK(hipEventRecord(e0, 0));
+  for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(stream_oop, grid, dim3(BLOCK), 0, 0, a, b, c, d, n2_env, chunk2);
+  CHK(hipEventRecord(e1, 0)); CHK(hipEventSynchronize(e1)); CHK(hipGetLastError());
+  float ms = 0; CHK(hipEventElapsedTime(&ms, e0, e1)); (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  return ms / reps * 1e3f;
+}
 float run(double2* a, double2* b) {
   const int envs = 64, nblk = 123, reps = 4; const long long n2_env = 500000;
   const long long chunk2 = ((n2_env + nblk - 1) / nblk + BLOCK - 1) / BLOCK * BLOCK;
@@ -77,6 +102,15 @@ int main(int argc, char** argv) {
       printf("  D=%g: %.0f", D, run((double2*)(base + w), (double2*)(base + w + d)));
     }
     printf("\n");
+  }
+  {
+    auto at = [&](double gib) { return (double2*)(base + ((size_t)(gib * 1024.0) << 20)); };
+    const double L4[][4] = {{1, 1.5, 2, 2.5}, {1, 33, 2, 34}, {1, 33, 81, 97}, {1, 33, 97, 81}, {1, 33, 17, 49}, {1, 97, 33, 113}, {1, 2, 33, 34}, {1, 33, 113, 129}};
+    for (auto& l : L4) {
+      if (((size_t)(l[3] * 1024.0) << 20) + arr > total || ((size_t)(l[2] * 1024.0) << 20) + arr > total) continue;
+      printf("out of place: read x at %g, v at %g GiB -> write at %g, %g GiB: %.0f %.0f us\n", l[0], l[1], l[2], l[3],
+             run_oop(at(l[0]), at(l[1]), at(l[2]), at(l[3])), run_oop(at(l[0]), at(l[1]), at(l[2]), at(l[3])));
+    }
   }
   // environments in G groups; group g's x at (1 + xs g) GiB, its v at (1 + vo + vs g) GiB
   struct Lay { const char* name; int G; double xs, vo, vs; };
