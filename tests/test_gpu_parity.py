@@ -960,6 +960,28 @@ def test_create_destroy_does_not_leak(oc, po):
     assert free0 - free1 < 64 << 20, (free0, free1)      # 25 cycles of ~40 MB each would show up as ~1 GB
 
 
+def test_placement_search_frees_what_it_does_not_keep(oc):
+    """States of 256 MB and more: pic_create allocates blocks until x and v stream well together and must give
+    back every block but the two it keeps, on success and when the handle is destroyed."""
+    import torch
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    state = 2 * 6 * 3_000_000 * 8                                   # 288 MB of float64 x and v
+    for _ in range(3):
+        env = oc.BatchedPIC(6, 3_000_000, 128, L=50.0, dt=0.1)
+        tried, kept, slowest = env._h.placement_info()
+        assert tried >= 1 and kept >= slowest > 0.0
+        env.sync()
+        held = free0 - torch.cuda.mem_get_info()[0]
+        assert state <= held < state + (96 << 20), (held, state)    # particles + meshes + staging, nothing of the search
+        env.reset_sampled("two-stream", seed=5)
+        env.step(None, 2)
+        assert env.bad_count() == 0
+        env.close()
+    torch.cuda.synchronize()
+    assert free0 - torch.cuda.mem_get_info()[0] < 32 << 20
+
+
 def test_two_handles_from_two_threads(oc, po):
     """Different handles are independent (own stream, own buffers); ctypes drops the GIL during calls."""
     import threading
