@@ -639,10 +639,11 @@ int pic_create(const pic_config* cfg, pic_handle** out) {
   h->nblk = (int)nblk;
 
   const size_t stride = (size_t)cfg->Ng + 2;
-  // LDS: 2 R meshes (sweep D deposits two) + the field tile; up to 4 mesh copies (waves w and w+4 share
-  // one: 8 copies measured no better) while the workgroup stays within 40 KB, i.e. 4 workgroups per CU
-  h->R = WAVES < 4 ? WAVES : 4;
-  while (h->R > 1 && 2 * h->R * stride * 8 + stride * h->esz > 40 * 1024) h->R >>= 1;
+  // LDS: 2 R meshes (sweep D deposits two) + the field tile.  R = 1: one mesh for the eight waves of a workgroup.  Copies per
+  // wave pair (R = 4, rounds 1-2) bought nothing at config 2 and cost 2-4 % where a step is short (more to sum and clear per
+  // workgroup); even with every particle in ONE cell a sweep is only 16 % slower, with 1 copy as with 4
+  // (profiles/experiments_r2.md 17, profiles/clustered.py)
+  h->R = 1;
   h->sweep_lds = 2 * h->R * stride * 8 + stride * h->esz;
   h->solve_lds = 2 * (size_t)cfg->Ng * sizeof(double);
   if (h->sweep_lds > 64 * 1024) {
@@ -658,7 +659,7 @@ int pic_create(const pic_config* cfg, pic_handle** out) {
     static const int shapes[4][3] = {{8, 4, 2048}, {8, 8, 4096}, {8, 10, 5120}, {8, 16, 8192}};
     for (const auto& sh : shapes)
       if (cfg->N <= sh[2]) { h->res_nw = sh[0]; h->res_ppt = sh[1]; break; }
-    h->res_R = 4;
+    h->res_R = 1;   // one mesh per workgroup: replicas cost more in node sums and clearing than they save in LDS atomic contention (experiments_r2.md 17)
     auto need = [&](int R) { return (size_t)2 * R * stride * 8 + 4 * (size_t)cfg->Ng * 8 + stride * h->esz; };
     while (h->res_R > 1 && need(h->res_R) > 48 * 1024) h->res_R >>= 1;
     h->res_lds = need(h->res_R);
