@@ -36,7 +36,7 @@ struct SweepArgs {
   long long chunk;    // particles per workgroup (multiple of BLOCK * VEC)
   int Ng;
   int nblk;           // workgroups per env
-  int R;              // LDS mesh replicas per workgroup (1, 2 or 4)
+  int R;              // LDS mesh replicas per workgroup (a power of two; the host uses 1: profiles/experiments_r2.md 17)
   int reverse;        // walk environments and chunks from the far end (alternates sweep to sweep)
   int fg;             // fractional bits of the fixed-point accumulators
   double magic;       // 1.5 * 2^(52 - fg): (w + magic) holds round(w 2^fg) in its low mantissa bits

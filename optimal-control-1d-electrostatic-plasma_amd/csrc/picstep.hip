@@ -21,8 +21,8 @@
 // Arithmetic inside a sub-stage keeps the reference's operand order and is compiled with
 // -ffp-contract=off so that fp64 results track NumPy to rounding (tests/ hold the bounds).
 //
-// Deposit: every workgroup owns LDS copies of its environment's mesh (one per wave pair, two sets in sweep D)
-// and accumulates with integer LDS atomics (weights as 2^-fg fixed point, or one packed word per particle for
+// Deposit: every workgroup owns an LDS copy of its environment's mesh (two in sweep D: final positions and the next step's
+// first drift) and accumulates with integer LDS atomics (weights as 2^-fg fixed point, or one packed word per particle for
 // single-precision CIC; pic_device.h), then adds its partial mesh to the environment's row [env][Ng] of a
 // global 64-bit fixed-point accumulator with memory-side integer atomics.  Integer sums are order-independent:
 // a step is bitwise reproducible and does not depend on the launch geometry.  Accumulator rows rotate through a
