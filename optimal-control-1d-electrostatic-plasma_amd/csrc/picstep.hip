@@ -621,7 +621,10 @@ int pic_create(const pic_config* cfg, pic_handle** out) {
     // ensembles are latency-bound (profiles/experiments_r2.md: N = 1e5 13 -> 98 workgroups 47 -> 28 us/step; N = 1e6
     // is best at 122 whatever the number of environments): one tile per workgroup, at most 64 workgroups per environment.
     const bool small = (double)cfg->N * cfg->num_envs <= 4.0e6 && cfg->N <= 131072;
-    const long long tiles_min = small ? 1 : 8;
+    long long tiles_min = small ? 1 : 8;
+    // one or two large environments: 4 tiles per workgroup, so that there is a workgroup for every CU (N = 1e6, one
+    // environment: 122 workgroups 64 us/step, 245 56 us, 489 63 us)
+    if (!small && (cfg->N + 8 * tile - 1) / (8 * tile) * cfg->num_envs < 256) tiles_min = 4;
     long long max_by_work = (cfg->N + tiles_min * tile - 1) / (tiles_min * tile);
     if (small && max_by_work > 64) max_by_work = 64;
     if (nblk > max_by_work) nblk = max_by_work;
