@@ -56,19 +56,33 @@ float run(int envs, int nblk, long long n2_env, int reps, int lds, double2* a, d
   return ms / reps * 1e3f;
 }
 
+static long long n2_env_for_pair(long long N) { return N / 2; }
+
 int main(int argc, char** argv) {
-  int envs = 64, reps = 10, contiguous = 0;
+  int envs = 64, reps = 10, contiguous = 0, pair = 0;
   long long N = 1000000;
   for (int i = 1; i < argc; ++i) {
     if (!strcmp(argv[i], "--envs")) envs = atoi(argv[++i]);
     else if (!strcmp(argv[i], "--particles")) N = atoll(argv[++i]);
     else if (!strcmp(argv[i], "--reps")) reps = atoi(argv[++i]);
+    else if (!strcmp(argv[i], "--pair")) pair = 1;               // x and v in two different 32 GiB regions of one 100 GiB block (the fast kind)
     else if (!strcmp(argv[i], "--contiguous")) contiguous = 1;   // one physically contiguous block (always of the slow kind)
   }
   const long long n2_env = N / 2;
   const size_t bytes = (size_t)envs * n2_env * 16;
   double2 *a, *b;
-  if (contiguous) {
+  if (pair) {
+    char* base; CHK(hipMalloc((void**)&base, (size_t)100 << 30));
+    a = reinterpret_cast<double2*>(base + ((size_t)1 << 30));
+    float best = 1e30f;
+    for (int gib : {33, 49, 65, 81, 97}) {
+      double2* cand = reinterpret_cast<double2*>(base + ((size_t)gib << 30));
+      CHK(hipMemset(a, 0, bytes)); CHK(hipMemset(cand, 0, bytes));
+      const float t = run<512, 1>(envs, 123, n2_env_for_pair(N), reps, 0, a, cand);
+      printf("v at %d GiB: %.1f us\n", gib, t);
+      if (t < best) { best = t; b = cand; }
+    }
+  } else if (contiguous) {
     void* p; CHK(hipExtMallocWithFlags(&p, 2 * bytes, hipDeviceMallocContiguous));
     a = static_cast<double2*>(p); b = a + bytes / 16;
   } else {
