@@ -483,8 +483,9 @@ const char* pic_last_error(pic_handle* h) { return h ? h->err.c_str() : g_create
 // For particle states that live in HBM (>= 256 MB) x and v are therefore two allocations: x first, then blocks of the same
 // size one after the other (they are laid down in sequence, 32 GiB is at most 64 blocks of config 2); every few blocks the
 // pair (x, block) is timed with a streaming pass, the first pair of the fast kind wins, everything else is freed
-// before pic_create returns.  Never more than a third of the free memory is held (the partner region can be 64 GiB away).  Smaller states keep x | v in one block
-// (they sit in the Infinity Cache, and the one-copy read-back of pic_get_particles wants them adjacent).
+// before pic_create returns.  Never more than a third of the free memory is held (the partner region can be 64 GiB away).
+// Smaller states keep x | v in one block (they sit in the Infinity Cache, and the one-copy read-back of
+// pic_get_particles wants them adjacent).  If no pair reaches kFastGBs the best one seen is kept.
 hipError_t alloc_particles(pic_handle* h, size_t pbytes) {
   constexpr size_t kMinBytes = (size_t)256 << 20;
   constexpr size_t kStride = (size_t)3 << 30;       // memory laid down between two timed candidates (a region is 32 GiB)
