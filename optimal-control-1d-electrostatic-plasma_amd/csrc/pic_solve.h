@@ -19,36 +19,39 @@ struct SolveIO {
   SolveOut out;
 };
 
-__global__ __launch_bounds__(SBLOCK) void field_solve_kernel(SolveIO io, SolveArgs a) {
-  extern __shared__ __align__(16) unsigned char smem_raw[];
-  double* sb = reinterpret_cast<double*>(smem_raw);   // b, then G_{j+1/2}
-  double* se = sb + a.Ng;                             // phi
-  __shared__ double ws[2 * SWAVES];
-  __shared__ double slot[2];
-
+// Density from the accumulator row (or the given right-hand side) of environment `env`, then solve_block.  Called by a whole
+// workgroup of SBLOCK threads; smem: 2 Ng doubles of LDS, ws: 2 SWAVES doubles, slot: 2 doubles.
+__device__ __forceinline__ void solve_environment(const SolveIO& io, int env, int Ng, int nblk, int fg, double scale, double n0,
+                                                  double dx, double N_over_L, unsigned char* smem, double* ws, double* slot) {
+  double* sb = reinterpret_cast<double*>(smem);       // b, then G_{j+1/2}
+  double* se = sb + Ng;                               // phi
   const int tid = threadIdx.x;
-  const int env = blockIdx.x;
-  const int Ng = a.Ng;
   const size_t row = (size_t)env * Ng;
-
   // density (interpolate.py:16-18), b = n - n0 (pic.py:116)
   if (io.acc) {
-    const double unit = ldexp(1.0, -a.fg);
+    const double unit = ldexp(1.0, -fg);
     for (int j = tid; j < Ng; j += SBLOCK) {
-      const double nj = ((double)io.acc[row + j] * unit) * a.scale;
+      const double nj = ((double)io.acc[row + j] * unit) * scale;
       if (io.n) io.n[row + j] = nj;
-      sb[j] = nj - a.n0;
+      sb[j] = nj - n0;
     }
   } else {
     for (int j = tid; j < Ng; j += SBLOCK) sb[j] = io.rhs[row + j];
   }
   double k = 0.0;
   if (io.ke_part)
-    for (int b = tid; b < a.nblk; b += SBLOCK) k += io.ke_part[(size_t)env * a.nblk + b];
+    for (int b = tid; b < nblk; b += SBLOCK) k += io.ke_part[(size_t)env * nblk + b];
   __syncthreads();
   SolveOut o = io.out;
   if (!io.ke_part) o.KE = nullptr;
-  solve_block<SWAVES>(o, env, Ng, a.dx, a.N_over_L, k, sb, se, ws, slot);
+  solve_block<SWAVES>(o, env, Ng, dx, N_over_L, k, sb, se, ws, slot);
+}
+
+__global__ __launch_bounds__(SBLOCK) void field_solve_kernel(SolveIO io, SolveArgs a) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  __shared__ double ws[2 * SWAVES];
+  __shared__ double slot[2];
+  solve_environment(io, blockIdx.x, a.Ng, a.nblk, a.fg, a.scale, a.n0, a.dx, a.N_over_L, smem_raw, ws, slot);
 }
 
 }  // namespace

@@ -2,6 +2,7 @@
 // LDS mesh into the global fixed-point accumulators, and sweep_kernel<P, A, SHAPE, STAGE> itself.
 #pragma once
 #include "pic_device.h"
+#include "pic_solve.h"
 
 namespace {
 
@@ -125,6 +126,10 @@ struct SweepIO {
   acc_t* zero1;
   double* ke_part;         // [env][nblk] sum of p^2 per workgroup (dual stages)
   unsigned long long* bad; // [1] count of non-finite / unrepresentable positions
+  // Sweep B inside a multi-step pic_step call: the post-step refresh of the PREVIOUS step (pic.py:145-146) -- nothing this
+  // step reads -- is done by one extra workgroup per environment (blockIdx.x == nblk) instead of a launch of its own.
+  // post.acc == null: no such workgroup.
+  SolveIO post;
 };
 
 template <typename P, typename A, int SHAPE, int STAGE>
@@ -150,14 +155,19 @@ __global__ __launch_bounds__(BLOCK) void sweep_kernel(typename P::X* __restrict_
   A* acc_all = reinterpret_cast<A*>(smem_raw);
   A* acc2_all = acc_all + (size_t)a.R * stride;
   T* Es = reinterpret_cast<T*>(smem_raw + (size_t)2 * a.R * stride * sizeof(A));
-  __shared__ double red[WAVES];
+  __shared__ double red[2 * WAVES];
   __shared__ double slot[2];       // mean of the prologue solve's gradient (16 B: keeps the dynamic LDS base aligned)
+
+  if (STAGE == ST_B && blockIdx.x == (unsigned)a.nblk) {      // the extra workgroup of its environment (host: only with io.post.acc)
+    solve_environment(io.post, blockIdx.y, Ng, a.nblk, a.fg, a.scale, a.n0, a.dx, a.N_over_L, smem_raw, red, slot);
+    return;
+  }
 
   const int tid = threadIdx.x;
   // Consecutive sweeps walk memory in opposite directions: what the previous sweep wrote last (still
   // in the 256 MB Infinity Cache) is what this one reads first.
   const int env = a.reverse ? (int)gridDim.y - 1 - (int)blockIdx.y : (int)blockIdx.y;
-  const int blk = a.reverse ? (int)gridDim.x - 1 - (int)blockIdx.x : (int)blockIdx.x;
+  const int blk = a.reverse ? a.nblk - 1 - (int)blockIdx.x : (int)blockIdx.x;
 
   typename P::X* xe = x + (size_t)env * a.ld;
   typename P::V* ve = v + (size_t)env * a.ld;

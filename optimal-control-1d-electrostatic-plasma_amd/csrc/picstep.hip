@@ -14,7 +14,9 @@
 //             deposit(next q1 = x' + (c1 p3) dt) into a second mesh
 //   solve   : n, E_mesh (no E_ext), phi, KE, PE, PE_reward        (pic.py:145-146, util.py:119-147)
 //
-// 4 launches and 3 read+write passes over the particles per step (96 B per particle-step in fp64).  Every
+// 4 launches and 3 read+write passes over the particles per step (96 B per particle-step in fp64); inside a multi-step
+// pic_step call the post-step solve of every step but the last rides with the next step's sweep B (one extra workgroup per
+// environment), so that a step there is 3 launches.  Every
 // sweep workgroup solves the field it gathers from in its own prologue (pic_sweep.h: prologue_field), from
 // the accumulator row the previous sweep filled.
 //
@@ -82,6 +84,7 @@ struct pic_handle {
   hipStream_t stream = nullptr;       // the stream every call works on (own_stream, or the caller's)
   hipStream_t own_stream = nullptr;   // created by pic_create, destroyed by pic_destroy
   bool v_separate = false;            // v is an allocation of its own (large states: alloc_particles)
+  int post_slot = -1;                 // ring row whose post-step solve rides with the next sweep B (inside pic_step only)
   int place_tried = 1;                // (x, v) placements pic_create timed (alloc_particles)
   double place_gbs[2] = {0.0, 0.0};   // streaming rate of the one kept and of the slowest one, GB/s
   void* x = nullptr;
@@ -180,7 +183,7 @@ void ring_retire(pic_handle* h, int slot) {
 
 template <typename P, typename A, int SHAPE, int STAGE>
 void launch_sweep_t(pic_handle* h, const SweepIO& io, void* x, void* v, const SweepArgs& a) {
-  dim3 grid(h->nblk, h->cfg.num_envs);
+  dim3 grid(h->nblk + ((STAGE == ST_B && io.post.acc) ? 1 : 0), h->cfg.num_envs);
   hipLaunchKernelGGL((sweep_kernel<P, A, SHAPE, STAGE>), grid, dim3(BLOCK), h->sweep_lds, h->stream,
                      static_cast<typename P::X*>(x), static_cast<typename P::V*>(v), io, a);
 }
@@ -250,7 +253,7 @@ void prof_end(pic_handle* h) {
 // out / out2: rows (or the probe accumulator) receiving the deposits.  The sweep also clears up to two
 // retired ring rows for later use.
 void launch_sweep(pic_handle* h, int stage, void* x, void* v, double c_prev, double c_cur, double d_cur,
-                  int in_slot, const double* ext, acc_t* out, acc_t* out2) {
+                  int in_slot, const double* ext, acc_t* out, acc_t* out2, int post_slot = -1) {
   SweepArgs a;
   a.N = h->cfg.N; a.ld = h->ld; a.chunk = h->chunk; a.Ng = h->cfg.Ng; a.nblk = h->nblk; a.R = h->R;
   a.reverse = (stage <= ST_D) ? (h->sweep_parity ^= 1) : 0;
@@ -260,7 +263,8 @@ void launch_sweep(pic_handle* h, int stage, void* x, void* v, double c_prev, dou
   a.c_prev = c_prev; a.c_cur = c_cur; a.d_cur = d_cur; a.c_next = h->cs[0];
   a.scale = h->scale; a.n0 = h->cfg.n0;
   a.to_units = 4294967296.0 / h->cfg.L;
-  SweepIO io;
+  a.N_over_L = (double)h->cfg.N / h->cfg.L;
+  SweepIO io{};
   io.acc_in = in_slot >= 0 ? ring_row(h, in_slot) : nullptr;
   io.ext = ext;
   io.acc_out = out;
@@ -274,6 +278,11 @@ void launch_sweep(pic_handle* h, int stage, void* x, void* v, double c_prev, dou
   io.zero1 = z[1] >= 0 ? ring_row(h, z[1]) : nullptr;
   io.ke_part = h->ke_part;
   io.bad = h->bad;
+  if (post_slot >= 0) {            // sweep B also carries the previous step's post-step refresh (pic_sweep.h: SweepIO::post)
+    io.post.acc = ring_row(h, post_slot);
+    io.post.ke_part = h->ke_part; io.post.n = h->n; io.post.out.E = h->E_mesh; io.post.out.phi = h->phi;
+    io.post.out.KE = h->KE; io.post.out.PE = h->PE; io.post.out.PEr = h->PEr;
+  }
   prof_begin(h, stage <= ST_D ? stage : 5);
   if (h->fmt == FMT_F64) launch_sweep_p<PosF64>(h, io, stage, x, v, a);
   else if (h->fmt == FMT_F32) launch_sweep_p<PosF32>(h, io, stage, x, v, a);
@@ -824,7 +833,10 @@ int pic_reset(pic_handle* h, const void* x0, const void* v0, int mem_kind) {
 
 // the sweeps of one environment step; `upto`: 1 = through sweep B, 2 = through C, 3 = whole step.  from: first
 // stage to run (1, 2, 3).  Each force evaluation takes `ext` (may differ per stage in the staged entry point).
-static void run_stages(pic_handle* h, int from, int upto, const double* ext) {
+// another_step_follows (the steps of one pic_step call but the last): the post-step solve of this step is not launched; the
+// next step's sweep B carries it in one extra workgroup per environment (its results -- n, E_mesh, phi, the energies --
+// are read by nothing inside the call, and the last step's solve is a launch of its own as ever).
+static void run_stages(pic_handle* h, int from, int upto, const double* ext, bool another_step_follows = false) {
   const double* c = h->cs;
   const double* d = h->ds;
   for (int st = from; st <= upto; ++st) {
@@ -834,7 +846,9 @@ static void run_stages(pic_handle* h, int from, int upto, const double* ext) {
         launch_sweep(h, ST_A, h->x, h->v, 0.0, c[0], 0.0, -1, nullptr, ring_row(h, h->q_slot), nullptr);
       }
       const int x1 = ring_take_clean(h);
-      launch_sweep(h, ST_B, h->x, h->v, c[0], c[1], d[1], h->q_slot, ext, ring_row(h, x1), nullptr);
+      launch_sweep(h, ST_B, h->x, h->v, c[0], c[1], d[1], h->q_slot, ext, ring_row(h, x1), nullptr, h->post_slot);
+      ring_retire(h, h->post_slot);
+      h->post_slot = -1;
       ring_retire(h, h->q_slot);
       h->q_slot = -1;
       h->stage_slot = x1;
@@ -848,7 +862,8 @@ static void run_stages(pic_handle* h, int from, int upto, const double* ext) {
       launch_sweep(h, ST_D, h->x, h->v, 0.0, c[3], d[3], h->stage_slot, ext, ring_row(h, f), ring_row(h, qn));
       ring_retire(h, h->stage_slot);
       h->stage_slot = -1;
-      launch_final_solve(h, f);
+      if (another_step_follows) h->post_slot = f;
+      else launch_final_solve(h, f);
       h->q_slot = qn;
     }
   }
@@ -896,7 +911,7 @@ int pic_step(pic_handle* h, const double* E_ext, int mem_kind, int nsteps) {
       drop_cached_deposits(h);       // the ring's q1 deposit belongs to the particles before these steps
     }
   } else {
-    for (int s = 0; s < nsteps; ++s) run_stages(h, 1, 3, ext);
+    for (int s = 0; s < nsteps; ++s) run_stages(h, 1, 3, ext, /*another_step_follows=*/s + 1 < nsteps);
   }
   HIPCHK(h, hipGetLastError());
   return PIC_OK;
