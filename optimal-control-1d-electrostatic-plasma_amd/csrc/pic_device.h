@@ -404,6 +404,8 @@ struct SolveOut {
   const double* ext;       // E_ext [env][Ng] added to E (force evaluations, util.py:102-103), or null
   double *E, *phi;         // [env][Ng]
   double *KE, *PE, *PEr;   // [env]
+  double* hist;            // [3][num_envs] KE, PE, PE_reward of this solve once more (one step's entry of an energy history), or null
+  int num_envs;
 };
 
 // From sb = b = n - n0 (filled by the caller, barrier included) to E (+ E_ext), zero-mean phi, PE = 0.5 sum(E^2) dx N/L
@@ -437,6 +439,11 @@ __device__ __forceinline__ void solve_block(const SolveOut& o, int env, int Ng, 
     if (o.PEr) o.PEr[env] = pe;
     if (o.PE) o.PE[env] = pe * N_over_L;
     if (o.KE) o.KE[env] = 0.5 * K;
+    if (o.hist) {
+      o.hist[env] = 0.5 * K;
+      o.hist[o.num_envs + env] = pe * N_over_L;
+      o.hist[2 * (size_t)o.num_envs + env] = pe;
+    }
   }
 }
 

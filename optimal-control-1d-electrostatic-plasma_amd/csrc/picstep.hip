@@ -85,6 +85,8 @@ struct pic_handle {
   hipStream_t own_stream = nullptr;   // created by pic_create, destroyed by pic_destroy
   bool v_separate = false;            // v is an allocation of its own (large states: alloc_particles)
   int post_slot = -1;                 // ring row whose post-step solve rides with the next sweep B (inside pic_step only)
+  double* hist_row = nullptr;         // where the NEXT post-step solve also records its three energies (step_recording), or null
+  double* post_hist_row = nullptr;    // the same for the solve that post_slot stands for
   int place_tried = 1;                // (x, v) placements pic_create timed (alloc_particles)
   double place_gbs[2] = {0.0, 0.0};   // streaming rate of the one kept and of the slowest one, GB/s
   void* x = nullptr;
@@ -282,6 +284,7 @@ void launch_sweep(pic_handle* h, int stage, void* x, void* v, double c_prev, dou
     io.post.acc = ring_row(h, post_slot);
     io.post.ke_part = h->ke_part; io.post.n = h->n; io.post.out.E = h->E_mesh; io.post.out.phi = h->phi;
     io.post.out.KE = h->KE; io.post.out.PE = h->PE; io.post.out.PEr = h->PEr;
+    io.post.out.hist = h->post_hist_row; io.post.out.num_envs = h->cfg.num_envs;
   }
   prof_begin(h, stage <= ST_D ? stage : 5);
   if (h->fmt == FMT_F64) launch_sweep_p<PosF64>(h, io, stage, x, v, a);
@@ -361,6 +364,7 @@ void launch_final_solve(pic_handle* h, int slot) {
   o.acc = ring_row(h, slot);
   o.ke_part = h->ke_part; o.n = h->n; o.out.E = h->E_mesh; o.out.phi = h->phi;
   o.out.KE = h->KE; o.out.PE = h->PE; o.out.PEr = h->PEr;
+  o.out.hist = h->hist_row; o.out.num_envs = h->cfg.num_envs;
   launch_solve(h, o);
   ring_retire(h, slot);
 }
@@ -862,7 +866,7 @@ static void run_stages(pic_handle* h, int from, int upto, const double* ext, boo
       launch_sweep(h, ST_D, h->x, h->v, 0.0, c[3], d[3], h->stage_slot, ext, ring_row(h, f), ring_row(h, qn));
       ring_retire(h, h->stage_slot);
       h->stage_slot = -1;
-      if (another_step_follows) h->post_slot = f;
+      if (another_step_follows) { h->post_slot = f; h->post_hist_row = h->hist_row; }
       else launch_final_solve(h, f);
       h->q_slot = qn;
     }
@@ -952,6 +956,13 @@ static int step_recording(pic_handle* h, const double* E_ext, int mem_kind, int 
       drop_cached_deposits(h);
     } else {
       const dim3 grid = aux_grid(h, E);
+      if (!ds) {       // energies only: every post-step solve records its own entry (the ones riding with sweep B included)
+        for (int s = 0; s < nsteps; ++s) {
+          h->hist_row = dh ? dh + (size_t)s * 3 * E : nullptr;
+          run_stages(h, 1, 3, ext, /*another_step_follows=*/s + 1 < nsteps);
+        }
+        h->hist_row = h->post_hist_row = nullptr;
+      } else
       for (int s = 0; s < nsteps && rc == PIC_OK; ++s) {
         rc = pic_step(h, ext, kind, 1);
         if (rc != PIC_OK) break;
