@@ -48,15 +48,32 @@ def synth_bump_on_tail_device(torch, num_envs, N, L, dtype, device, seed, a=0.2,
     return x.to(dtype).contiguous(), v.to(dtype).contiguous()
 
 
+PMC_SUMMARY = "r3_summary.json"          # committed rocprofv3 evidence of this round (profiles/collect.sh)
+# VALU issue ceiling for the resident schedule's roofline: one wave-instruction per SIMD every 2 cycles (the 32-bit rate of a
+# SIMD-32; float64 instructions take 4), 4 SIMDs x 256 CUs at the 2.4 GHz peak clock (MI355X_MICROARCH.md)
+VALU_PEAK_GINST_S = 256 * 4 * 2.4 / 2
+
+
 def pmc_traffic(kernel, args, E, N, Ng):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (FETCH_SIZE x2 +
     WRITE_SIZE, profiles/summarize.py) -- only when they were taken on this exact workload."""
-    path = os.path.join(ROOT, "profiles", "r2_summary.json")
+    path = os.path.join(ROOT, "profiles", PMC_SUMMARY)
     if not os.path.exists(path) or (E, N, Ng, args.dtype, args.positions) != (64, 1_000_000, 256, "float64", "float"):
         return None, None
     val = json.load(open(path)).get("kernels", {}).get(kernel, {}).get("hbm_bytes_per_launch")
-    return val, "profiles/r2_summary.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, " \
+    return val, f"profiles/{PMC_SUMMARY} (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, " \
                 "not measured by this run)"
+
+
+def pmc_valu_per_particle_step(args, N, Ng):
+    """VALU wave-instructions per particle-step of the resident kernel (SQ_INSTS_VALU of a rocprofv3 --pmc pass divided by the
+    particle-steps of the launch, profiles/pmc_resident.sh), for the particle format of this run; None if not collected."""
+    path = os.path.join(ROOT, "profiles", PMC_SUMMARY)
+    if not os.path.exists(path):
+        return None, None
+    table = json.load(open(path)).get("resident_valu_wave_insts_per_particle_step", {})
+    key = f"{args.dtype}/{args.positions}/N={N}/Ng={Ng}"
+    return table.get(key), f"profiles/{PMC_SUMMARY}: SQ_INSTS_VALU per launch / particle-steps per launch, {key}"
 
 
 def _cpu_env(args):
@@ -131,10 +148,26 @@ def main():
     ap.add_argument("--actions", type=int, default=0, metavar="M",
                     help="a new random action (2M Fourier coefficients in [-1.25, 1.25], SURVEY 8d) for every environment and "
                          "step, turned into E_ext by the device actuator (BASELINE config 3); 0 = no control")
+    ap.add_argument("--config", type=int, default=0, choices=[0, 1, 2, 3, 4, 5],
+                    help="BASELINE.json configuration by number, at its single-GPU share (overrides the workload flags): "
+                         "1 = N=1e4/Ng=128/1 env fp64; 2 = the default; 3 = two-stream N=1e6/Ng=512/128 envs fp32 fixed-point "
+                         "positions, a new random action every step; 4 = N=4e6/Ng=1024/64 envs fp64; 5 = N=1e7/Ng=256/128 envs fp32")
+    ap.add_argument("--steady-steps", type=int, default=200,
+                    help="steps of a second, longer region timed after the headline one and printed as `steady_state` (0 = skip)")
+    ap.add_argument("--per-step-calls", action="store_true",
+                    help="with --actions: one pic_step_actions call per step (a trainer's loop: the action of step s is only known "
+                         "after step s-1) instead of ONE pic_step_actions_traj call for all steps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-procs", type=int, default=1, help="processes (one env each) for the CPU baseline")
     ap.add_argument("--profile-steps", type=int, default=-1, help="steps of the event-bracketed pass (-1 = --steps)")
     args = ap.parse_args()
+    presets = {1: dict(envs=1, particles=10_000, mesh=128),
+               2: dict(),
+               3: dict(envs=128, mesh=512, dtype="float32", positions="fixed32", init="two-stream", actions=3),
+               4: dict(particles=4_000_000, mesh=1024),
+               5: dict(envs=128, particles=10_000_000, dtype="float32")}
+    for k, val in presets.get(args.config, {}).items():
+        setattr(args, k, val)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -165,6 +198,11 @@ def main():
         import torch.distributed as dist
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device(f"cuda:{dev_index}"))
+            # one rank per GPU over RCCL, or this is not the run the line claims to be
+            if dist.get_backend() != "nccl":
+                raise SystemExit(f"process group backend is {dist.get_backend()!r}, not nccl (RCCL)")
+            if world > torch.cuda.device_count():
+                raise SystemExit(f"{world} ranks but only {torch.cuda.device_count()} GPUs visible: ranks would share a device")
         else:
             dist.init_process_group(backend)
 
@@ -195,17 +233,20 @@ def main():
         env.set_actuator(E_field(L, Ng, args.actions))
         g = torch.Generator(device=f"cuda:{local_rank}")
         g.manual_seed(4321 + rank)
-        nact = max(args.steps, args.warmup, 1)
+        nact = max(args.steps, args.warmup, args.steady_steps, args.profile_steps, 1)
         acts = (torch.rand((nact, E, 2 * args.actions), generator=g, device=f"cuda:{local_rank}", dtype=torch.float64) * 2.5 - 1.25)
         torch.cuda.synchronize()
 
     def run_steps(k):
-        """k environment steps: one pic_step call, or (with --actions) k calls that each build E_ext from a new action."""
+        """k environment steps in one call: pic_step, or (with --actions) pic_step_actions_traj with a new action for every
+        step, E_ext built from it inside the field phases; --per-step-calls: k pic_step_actions calls instead."""
         if acts is None:
             env.step(None, nsteps=k)
-        else:
+        elif args.per_step_calls:
             for i in range(k):
                 env.step_actions_device(acts[i].data_ptr(), 1)
+        else:
+            env._h.step_actions_traj_device(acts.data_ptr(), k)
 
     run_steps(args.warmup)
     if cdev != "cpu":
@@ -248,7 +289,18 @@ def main():
     drift = float(np.max(np.abs((ke + pe) / (ke0 + pe0) - 1)))
     bad = env.bad_count()
 
-    # Per-kernel durations: the same K steps again, every launch bracketed by HIP events on the
+    # A second, longer region on this rank's own clock: the first ~30 steps after an idle GPU run a few per cent slow (clock
+    # ramp), so the headline K-step figure of a short run understates what a rollout sees.  Not part of `value`.
+    steady = None
+    if rank == 0 and args.steady_steps > 0:
+        env.sync()
+        t1 = time.perf_counter()
+        run_steps(args.steady_steps)
+        env.sync()
+        steady = {"steps": args.steady_steps, "ms_per_step": (time.perf_counter() - t1) / args.steady_steps * 1e3}
+        steady["value"] = N * E / (steady["ms_per_step"] * 1e-3)
+
+    # Per-kernel durations: K steps again, every launch bracketed by HIP events on the
     # library's own stream (the brackets cost ~4 % of a step, so they stay out of `value`).
     roof = None
     kernels = {}
@@ -259,7 +311,7 @@ def main():
         env.profile(True)
         env.sync()
         t1 = time.perf_counter()
-        run_steps(min(psteps, args.steps) if acts is not None else psteps)
+        run_steps(psteps)
         env.sync()
         ms_per_step_events = (time.perf_counter() - t1) / psteps * 1e3
         prof = env.profile_read()
@@ -268,23 +320,34 @@ def main():
         for k, (ms, cnt) in prof.items():
             kernels[k] = {"avg_ms": ms / cnt, "launches": cnt}
             if k == "resident":
-                kernels[k]["steps_per_launch"] = psteps
+                kernels[k]["steps_per_launch"] = 1 if (acts is not None and args.per_step_calls) else psteps
         if "resident" in prof:
-            # small environments: the whole call is one launch that reads and writes the particles once and keeps
-            # them in registers in between; the step is bound by latency and VALU issue, not by HBM
+            # Small environments: the whole call is one launch that keeps the particles in registers; HBM sees them once at
+            # entry and once at exit.  What bounds it is VALU issue and dependent latency of the ONE CU an environment
+            # occupies, so the roofline is priced in VALU wave-instructions, not bytes.
             dom = "resident"
-            alg_bytes = 4 * esz * N * E
+            avg_s = prof[dom][0] / prof[dom][1] * 1e-3
+            spl = kernels[dom]["steps_per_launch"]
+            w, w_src = pmc_valu_per_particle_step(args, N, Ng)
+            ach = None if w is None else w * N * E * spl / avg_s / 1e9
+            cus = min(E, 256)
+            roof = {"bound": "valu+latency", "kernel": dom, "achieved": ach, "peak": VALU_PEAK_GINST_S, "unit": "Gwave-inst/s",
+                    "frac": None if ach is None else ach / VALU_PEAK_GINST_S,
+                    "frac_of_the_CUs_in_use": None if ach is None else ach / (VALU_PEAK_GINST_S * cus / 256),
+                    "traffic": None, "valu_wave_insts_per_particle_step": w, "counter_source": w_src,
+                    "avg_launch_ms": avg_s * 1e3, "steps_per_launch": spl,
+                    "ms_per_step_with_event_brackets": ms_per_step_events, "measured_inplace_copy_GBs": copy_gbs}
         else:
             dom = max((k for k in prof if k in SWEEP_WORDS), key=lambda k: prof[k][0])
             alg_bytes = SWEEP_WORDS[dom] * esz * N * E
-        avg_s = prof[dom][0] / prof[dom][1] * 1e-3
-        ach = alg_bytes / avg_s / 1e9
-        traffic, traffic_source = pmc_traffic(dom, args, E, N, Ng)
-        roof = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
-                "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_s * 1e3,
-                "ms_per_step_with_event_brackets": ms_per_step_events,
-                "measured_inplace_copy_GBs": copy_gbs}
+            avg_s = prof[dom][0] / prof[dom][1] * 1e-3
+            ach = alg_bytes / avg_s / 1e9
+            traffic, traffic_source = pmc_traffic(dom, args, E, N, Ng)
+            roof = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+                    "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_s * 1e3,
+                    "ms_per_step_with_event_brackets": ms_per_step_events,
+                    "measured_inplace_copy_GBs": copy_gbs}
 
     total_ps = N * E * world * args.steps
     value = total_ps / elapsed
@@ -296,7 +359,8 @@ def main():
         "config": {"workload": f"{'configs[1]: ' if (N, Ng, E, args.dtype) == (1_000_000, 256, 64, 'float64') else ''}"
                                f"{args.init}, N={N}, Ng={Ng}, {E} envs per GPU, {args.dtype}"
                                f"{' (fixed-point positions)' if args.positions == 'fixed32' else ''}, "
-                               + (f"a new random action of {2 * args.actions} coefficients per step through the device actuator"
+                               + (f"a new random action of {2 * args.actions} coefficients per step through the device actuator "
+                                  + ("(one pic_step_actions call per step)" if args.per_step_calls else "(one pic_step_actions_traj call)")
                                   if args.actions > 0 else "no control (E_ext = None)") + ", Yoshida-4 step = PIC.update_state",
                    "envs_per_gpu": E, "particles_per_env": N, "mesh": Ng, "dt": env.dt, "schedule": env._h.schedule(),
                    "sharding": f"{world} x {E} envs, all-gather of returns only"},
@@ -304,11 +368,13 @@ def main():
         # and on SURVEY 8d's algorithmic count (14 words; > the first because sweep A's read is not made at all)
         "hbm_frac_of_step": value / world * MOVED_BYTES_PER_PARTICLE_STEP[args.dtype] / (HBM_PEAK_GBS * 1e9),
         "algorithmic_frac_of_step": value / world * ALGORITHMIC_BYTES_PER_PARTICLE_STEP[args.dtype] / (HBM_PEAK_GBS * 1e9),
+        "steady_state": steady,
         "per_rank_ms_per_step": per_rank_ms, "returns_all_gather_ms": gather_ms,
+        "collective_backend": None if dist is None else dist.get_backend(), "gpus_visible": torch.cuda.device_count(),
         "energy_drift": drift, "bad_positions": bad, "mean_return": float(returns.mean().item()),
         # pic_create's search for two different HBM regions for x and v: (x, v) placements timed, bare-stream GB/s of the pair
         # kept and of the slowest pair seen
-        "placement": dict(zip(("pairs_timed", "kept_GBs", "slowest_GBs"), env._h.placement_info())),
+        "placement": dict(zip(("pairs_timed", "kept_GBs", "slowest_GBs", "seconds"), env._h.placement_info())),
         "roofline": roof, "kernels": kernels,
     }
     if rank == 0:

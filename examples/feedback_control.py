@@ -3,8 +3,11 @@
 Shape of the reference's run_feedback.py:130-168: every step the first `max_mode` Fourier modes of the
 self-consistent field become the action (cos coefficients -Re E_k, sin coefficients +Im E_k), the
 actuator turns the action into an external field and the environment is stepped with it.  Here the
-modes, the actuator product and the step all run on the MI355X; per step only `2 * max_mode` numbers
-per environment cross the host boundary.
+modes, the actuator product and the step all run on the MI355X.  With the reference's unit gain the whole
+loop is ONE call (`BatchedPIC.step_feedback` -> pic_step_feedback: the action of every step is computed on the
+device from the field the step before left, nothing crosses the host boundary until the recorded energies
+and actions come back at the end); with another gain the action passes through the host every step
+(`2 * max_mode` numbers per environment).
 
     python examples/feedback_control.py [num_envs] [N] [steps]
 """
@@ -33,6 +36,17 @@ def run(num_envs=4, N=20000, steps=400, N_mesh=128, L=50.0, max_mode=5, gain=1.0
     ctrl.set_actuator(E_field(L, N_mesh, max_mode))
     for env in (free, ctrl):
         env.reset(x0, v0)
+    if gain == 1.0:
+        rec = ctrl.step_feedback(steps, actions=True, history=True)     # the closed loop, one call
+        pe_free = free.step_history(None, steps)[2].mean(axis=1)
+        pe_ctrl = rec["PE_reward"].mean(axis=1)
+        effort = np.abs(rec["actions"]).max(axis=(1, 2))
+        if verbose:
+            for k in range(0, steps, 50):
+                print(f"step {k:4d}  field energy: free {pe_free[k]:.4e}  controlled {pe_ctrl[k]:.4e}  max|action| {effort[k]:.3f}")
+        free.close()
+        ctrl.close()
+        return pe_free, pe_ctrl, effort
     pe_free, pe_ctrl, effort = [], [], []
     for k in range(steps):
         action = gain * ctrl.feedback_actions(max_mode)               # [num_envs, 2 max_mode], from device modes

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define PICSTEP_ABI_VERSION 2
+#define PICSTEP_ABI_VERSION 3
 
 enum { PIC_F64 = 0, PIC_F32 = 1 };           /* particle dtype (velocities; positions too unless fixed point) */
 enum { PIC_POS_FLOAT = 0,                    /* positions stored in the particle dtype                         */
@@ -36,6 +36,8 @@ enum { PIC_ACC_AUTO = 0,                     /* deposit accumulator: library's c
        PIC_ACC_PACKED = 2,                    /* float32 particles, CIC: (count, sum of w_r) per cell in one word     */
        PIC_ACC_F64 = 3 };                     /* float64 particles: float64 running sums in LDS (ds_add_f64)          */
 enum { PIC_CIC = 0, PIC_TSC = 1 };           /* src/env/interpolate.py:4 (CIC), :22 (TSC)     */
+enum { PIC_PLACE_AUTO = 0,                   /* large states: look for x and v in two different regions of HBM (pic_placement_info) */
+       PIC_PLACE_OFF = 1 };                   /* no search: x | v in one allocation                                                 */
 enum { PIC_HOST = 0, PIC_DEVICE = 1 };       /* where a caller buffer lives                   */
 
 enum {
@@ -73,6 +75,7 @@ typedef struct pic_config {
   int32_t position_dtype;  /* PIC_POS_FLOAT | PIC_POS_FIXED32 (needs particle_dtype PIC_F32).  Fixed-point positions
                               are handed over and returned as float32 like any float32 particle array; on the device
                               they are uint32 (pic_device_ptrs' x)                                                  */
+  int32_t placement;       /* PIC_PLACE_AUTO | PIC_PLACE_OFF: see pic_placement_info                                */
 } pic_config;
 
 typedef struct pic_handle pic_handle;
@@ -186,11 +189,33 @@ int pic_solve_poisson(pic_handle* h, const double* rhs, double* phi, double* E_m
 
 /* Device-side actuator, E_field (src/control/actuator.py:4-63).  pic_set_actuator uploads the host
  * mirror's basis tables, basis_cos / basis_sin [Ng][max_mode] float64 (they carry the reference's
- * linspace(0, L, Ng) mesh).  pic_step_actions computes E_ext = basis_cos @ a[:M] + basis_sin @ a[M:]
- * (actuator.py:54-63) for every environment from actions [num_envs][2*max_mode] float64 (host or
- * device) and runs nsteps x update_state with it -- no mesh-sized host->device copy per step. */
+ * linspace(0, L, Ng) mesh).  pic_step_actions runs nsteps x update_state under E_ext = basis_cos @ a[:M] +
+ * basis_sin @ a[M:] (actuator.py:54-63), a = actions [num_envs][2*max_mode] float64 (host or device), held for the
+ * nsteps.  The field is built inside the field phase of the kernels that use it: a controlled step costs no launch and
+ * no mesh-sized copy more than an uncontrolled one. */
 int pic_set_actuator(pic_handle* h, int max_mode, const double* basis_cos, const double* basis_sin);
 int pic_step_actions(pic_handle* h, const double* actions, int mem_kind, int nsteps);
+
+/* A rollout with a NEW action every step in one call -- the inner loop of the trainers (src/control/rl/ddpg.py:421-468,
+ * ppo.py:307-372, sac.py:328-396) once the actions are known, and PIC.simulate with an action trajectory:
+ * actions [nsteps][num_envs][2*max_mode] float64 (host or device); step s runs under actions[s].  Resident schedule: one launch
+ * for all steps; streaming: three launches per step, as pic_step(nsteps).  hist: NULL, or host [nsteps][3][num_envs] = KE, PE,
+ * PE_reward after each step (the call then returns when it has arrived; with NULL it is asynchronous like pic_step). */
+int pic_step_actions_traj(pic_handle* h, const double* actions, int mem_kind, int nsteps, double* hist);
+
+/* The same with the fields given on the mesh: PIC.simulate(E_external_traj) (pic.py:175-223, E_external_traj[i] of step i).
+ * E_ext_traj [nsteps][num_envs][Ng] float64 (host or device); hist as above; snap: NULL, or the particle snapshots of
+ * pic_step_snapshots. */
+int pic_step_ext_traj(pic_handle* h, const double* E_ext_traj, int mem_kind, int nsteps, double* hist, void* snap);
+
+/* nsteps of the linear feedback loop of run_feedback.py:130-168 on the device: before every step the actuator coefficients are
+ * set to (-Re E_m, +Im E_m), m = 1..max_mode, of the Fourier modes (src/interpret/spectrum.py:16) of the mesh field the
+ * previous step left (the current E_mesh for the first step) -- compute_E_k_spectrum, E_field.update_E, E_field.compute_E and
+ * PIC.update_state of one loop iteration without leaving the device.  max_mode must be the actuator's (pic_set_actuator) and
+ * at most 16.  actions_out: NULL, or host [nsteps][num_envs][2*max_mode] = the coefficients each step ran under (cos half, sin
+ * half: the reference's coeff_cos / coeff_sin lists); hist as above.  Bit for bit what the host loop pic_get_modes ->
+ * pic_step_actions gives. */
+int pic_step_feedback(pic_handle* h, int max_mode, int nsteps, double* actions_out, double* hist);
 
 /* Rows 1..max_mode of compute_E_k_spectrum (src/interpret/spectrum.py:16) for the current E_mesh:
  * Ek[m] = fft(E_mesh)[m] / Ng * 2, re / im [num_envs][max_mode] float64 (host or device, any may be
@@ -203,6 +228,12 @@ int pic_get_modes(pic_handle* h, int max_mode, double* re, double* im, int mem_k
  * np.histogram2d's bins for range [[0, L], [vmin, vmax]] -- same edge rules (edges lo + i*step,
  * last edge inclusive, out-of-range values dropped).  f = counts * n0 / dx / dv / N on the host. */
 int pic_phase_histogram(pic_handle* h, int nbins, double vmin, double vmax, uint32_t* counts);
+
+/* The KL cost built on it, Reward.compute_kl_divergence (src/control/rl/reward.py:43-46 -> estimate_KL_divergence,
+ * objective.py:16-18), for every environment at once: kl[e] = sum_ij rel_entr(f_e[i][j], feq[i][j] + 1e-12) dx dv with
+ * f_e = counts_e n0 / dx / dv / N, dx = L / nbins, dv = (vmax - vmin) / nbins; feq host [nbins][nbins] float64 (the target
+ * density, estimate_f of the initial state), kl host [num_envs].  Histogram and reduction stay on the device. */
+int pic_phase_kl(pic_handle* h, int nbins, double vmin, double vmax, const double* feq, double* kl);
 
 /* Per-kernel timing with HIP events on the handle's stream (bench.py's roofline leg).
  * kinds: 0..3 = sweeps A..D, 4 = field solve. ms_sum / launches are arrays of 8. */
@@ -226,13 +257,19 @@ int pic_own_stream(pic_handle* h);
 int pic_schedule(pic_handle* h);
 
 /* Particle states of 256 MB and more: x and v are two allocations, and pic_create times a streaming pass over (x, candidate
- * block for v) for a series of candidate blocks until the pair is of the fast kind: on MI355X two arrays stream together at
- * 6.05 TB/s when they lie in different 32 GiB regions of HBM and at 5.25 TB/s when they share one.
- * The search allocates blocks of the state's size in sequence and may hold up to a third of the device's free memory while
- * pic_create runs; everything but x and v is freed before it returns (0.01 - 0.4 s).
- * -> how many pairs were timed (1 with rates 0 = small state, nothing timed), the read+write rate of the pair kept and of the
- * slowest pair seen, in GB/s. */
-int pic_placement_info(pic_handle* h, int* candidates, double* kept_gbytes_per_s, double* slowest_gbytes_per_s);
+ * block for v) for a series of candidate blocks: on MI355X two arrays stream together at 6.05 TB/s when they lie in different
+ * 32 GiB regions of HBM and at 5.25 TB/s when they share one.  The search stops as soon as the best pair seen is
+ * 10 % faster than the slowest seen, after six timed pairs without an improvement, after 100 ms, or when a third of the
+ * device's free memory is held -- whichever comes first; no absolute rate enters.
+ * What a co-resident allocator (torch's caching allocator, another handle on another thread or rank of the same device) sees:
+ * while pic_create runs, blocks of the state's size are allocated one after the other and up to a third of the free memory is
+ * held; all but x and v are freed before it returns.  An allocation made by someone else in that window can fail for lack of
+ * memory although it would fit a moment later: create large handles before filling the device, serialise creates per device, or
+ * set pic_config.placement = PIC_PLACE_OFF (x | v in one block, no search, nothing held; config 2 then steps ~10 % slower when
+ * the block falls into one region).  Results do not depend on the placement.
+ * -> how many pairs were timed (1 with rates 0 = small state or search off, nothing timed), the read+write rate of the pair kept
+ * and of the slowest pair seen, in GB/s, and the wall time the search took; any pointer may be NULL. */
+int pic_placement_info(pic_handle* h, int* candidates, double* kept_gbytes_per_s, double* slowest_gbytes_per_s, double* seconds);
 
 int pic_sync(pic_handle* h);
 /* Number of particle positions found non-finite or out of range by the last sweeps (0 = healthy). */

@@ -15,7 +15,7 @@ PIC_POS_FLOAT, PIC_POS_FIXED32 = 0, 1
 PIC_ACC_AUTO, PIC_ACC_FIX64, PIC_ACC_PACKED, PIC_ACC_F64 = 0, 1, 2, 3
 PIC_CIC, PIC_TSC = 0, 1
 PIC_HOST, PIC_DEVICE = 0, 1
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 # accum_dtype spellings of the Python layer -> PIC_ACC_*
 ACCUMULATORS = {None: PIC_ACC_AUTO, "auto": PIC_ACC_AUTO, "fix64": PIC_ACC_FIX64, "fixed": PIC_ACC_PACKED,
@@ -31,7 +31,7 @@ class PicConfig(C.Structure):
         ("L", C.c_double), ("n0", C.c_double), ("dt", C.c_double), ("gamma", C.c_double),
         ("particle_dtype", C.c_int32), ("accum_dtype", C.c_int32), ("interpol", C.c_int32),
         ("device_id", C.c_int32), ("blocks_per_env", C.c_int32), ("env_index_base", C.c_int32),
-        ("position_dtype", C.c_int32),
+        ("position_dtype", C.c_int32), ("placement", C.c_int32),
     ]
 
 
@@ -68,13 +68,17 @@ SIGNATURES = {
     "pic_profile_read": [_vp, _dp, _i64p],
     "pic_set_actuator": [_vp, C.c_int, _vp, _vp],
     "pic_step_actions": [_vp, _vp, C.c_int, C.c_int],
+    "pic_step_actions_traj": [_vp, _vp, C.c_int, C.c_int, _vp],
+    "pic_step_ext_traj": [_vp, _vp, C.c_int, C.c_int, _vp, _vp],
+    "pic_step_feedback": [_vp, C.c_int, C.c_int, _vp, _vp],
     "pic_get_modes": [_vp, C.c_int, _vp, _vp, C.c_int],
     "pic_phase_histogram": [_vp, C.c_int, C.c_double, C.c_double, _vp],
+    "pic_phase_kl": [_vp, C.c_int, C.c_double, C.c_double, _vp, _vp],
     "pic_stream_probe": [_vp, C.c_int, _dp],
     "pic_set_stream": [_vp, _vp],
     "pic_own_stream": [_vp],
     "pic_schedule": [_vp],
-    "pic_placement_info": [_vp, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double)],
+    "pic_placement_info": [_vp, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)],
     "pic_sync": [_vp],
     "pic_bad_count": [_vp, _i64p],
     "pic_last_error": [_vp],
@@ -141,7 +145,7 @@ class Handle:
 
     def __init__(self, N, Ng, num_envs=1, L=50.0, n0=1.0, dt=0.1, gamma=5.0, particle_dtype="float64",
                  accum_dtype=None, interpol="CIC", device_id=0, blocks_per_env=0, env_index_base=0,
-                 position_dtype=None):
+                 position_dtype=None, placement="auto"):
         self.lib = load()
         pd = {"float64": PIC_F64, "float32": PIC_F32}[str(np.dtype(particle_dtype))]
         # LDS mesh accumulator (include/picstep.h PIC_ACC_*).  None: the library's choice -- the packed word for
@@ -155,7 +159,8 @@ class Handle:
             raise ValueError(f"position_dtype must be 'float', 'fixed32' or None, not {position_dtype!r}")
         self.cfg = PicConfig(int(N), int(Ng), int(num_envs), float(L), float(n0), float(dt), float(gamma), pd,
                              ACCUMULATORS[key], {"CIC": PIC_CIC, "TSC": PIC_TSC}[interpol], int(device_id),
-                             int(blocks_per_env), int(env_index_base), POSITION_FORMATS[pkey])
+                             int(blocks_per_env), int(env_index_base), POSITION_FORMATS[pkey],
+                             {"auto": 0, "off": 1}[placement])
         self.fixed_positions = POSITION_FORMATS[pkey] == PIC_POS_FIXED32
         self.N, self.Ng, self.num_envs = int(N), int(Ng), int(num_envs)
         self.dtype = np.dtype(particle_dtype)
@@ -228,10 +233,11 @@ class Handle:
         return "resident" if self.lib.pic_schedule(self._h) == 1 else "streaming"
 
     def placement_info(self):
-        """((x, v) placements pic_create timed, GB/s of the pair kept, GB/s of the slowest pair); (1, 0, 0) for small states."""
-        n, kept, slow = C.c_int(), C.c_double(), C.c_double()
-        self._chk(self.lib.pic_placement_info(self._h, C.byref(n), C.byref(kept), C.byref(slow)))
-        return n.value, kept.value, slow.value
+        """((x, v) placements pic_create timed, GB/s of the pair kept, GB/s of the slowest pair, seconds the search took);
+        (1, 0, 0, 0) for small states and with placement="off"."""
+        n, kept, slow, sec = C.c_int(), C.c_double(), C.c_double(), C.c_double()
+        self._chk(self.lib.pic_placement_info(self._h, C.byref(n), C.byref(kept), C.byref(slow), C.byref(sec)))
+        return n.value, kept.value, slow.value, sec.value
 
     def particles(self):
         x = np.empty((self.num_envs, self.N), dtype=self.dtype)
@@ -358,6 +364,49 @@ class Handle:
     def step_actions_device(self, actions_ptr, nsteps=1):
         self._chk(self.lib.pic_step_actions(self._h, _ptr(int(actions_ptr)), PIC_DEVICE, int(nsteps)))
 
+    def _hist_out(self, nsteps, history):
+        return np.empty((int(nsteps), 3, self.num_envs)) if history else None
+
+    def step_actions_traj(self, actions, history=False):
+        """One step per row of actions [nsteps][num_envs][2*max_mode], all in one call (pic_step_actions_traj).
+        history=True: returns (KE, PE, PE_reward), each [nsteps][num_envs]; otherwise asynchronous, returns None."""
+        a = np.ascontiguousarray(np.asarray(actions, dtype=np.float64))
+        a = a.reshape(-1, self.num_envs, 2 * self.max_mode)
+        hist = self._hist_out(a.shape[0], history)
+        self._chk(self.lib.pic_step_actions_traj(self._h, _ptr(a), PIC_HOST, a.shape[0], _ptr(hist)))
+        return None if hist is None else (hist[:, 0], hist[:, 1], hist[:, 2])
+
+    def step_actions_traj_device(self, actions_ptr, nsteps):
+        """actions: device pointer to [nsteps][num_envs][2*max_mode] float64; asynchronous on the handle's stream."""
+        self._chk(self.lib.pic_step_actions_traj(self._h, _ptr(int(actions_ptr)), PIC_DEVICE, int(nsteps), None))
+
+    def step_ext_traj(self, E_ext_traj, history=False, snapshots=False):
+        """One step per row of E_ext_traj [nsteps][num_envs][Ng] (pic_step_ext_traj): PIC.simulate(E_external_traj).
+        Returns None, (KE, PE, PE_reward), or (x, v, KE, PE, PE_reward) with snapshots=True."""
+        e = np.ascontiguousarray(np.asarray(E_ext_traj, dtype=np.float64)).reshape(-1, self.num_envs, self.Ng)
+        k = e.shape[0]
+        hist = self._hist_out(k, history or snapshots)
+        snap = np.empty((k, 2, self.num_envs, self.N), dtype=self.dtype) if snapshots else None
+        self._chk(self.lib.pic_step_ext_traj(self._h, _ptr(e), PIC_HOST, k, _ptr(hist), _ptr(snap)))
+        if snapshots:
+            return snap[:, 0], snap[:, 1], hist[:, 0], hist[:, 1], hist[:, 2]
+        return None if hist is None else (hist[:, 0], hist[:, 1], hist[:, 2])
+
+    def step_feedback(self, nsteps, actions=False, history=False):
+        """nsteps of the linear feedback loop on the device (pic_step_feedback; the actuator's max_mode).  Returns a dict with
+        "actions" [nsteps][num_envs][2*max_mode] and / or "KE", "PE", "PE_reward" [nsteps][num_envs] as asked for; with
+        neither the call is asynchronous and returns None."""
+        k = int(nsteps)
+        act = np.empty((k, self.num_envs, 2 * self.max_mode)) if actions else None
+        hist = self._hist_out(k, history)
+        self._chk(self.lib.pic_step_feedback(self._h, self.max_mode, k, _ptr(act), _ptr(hist)))
+        out = {}
+        if act is not None:
+            out["actions"] = act
+        if hist is not None:
+            out.update(KE=hist[:, 0], PE=hist[:, 1], PE_reward=hist[:, 2])
+        return out or None
+
     def set_stream(self, hip_stream):
         """hip_stream: integer hipStream_t (e.g. torch.cuda.current_stream().cuda_stream; 0 = the default stream)."""
         self._chk(self.lib.pic_set_stream(self._h, C.c_void_p(int(hip_stream)) if hip_stream else None))
@@ -378,6 +427,15 @@ class Handle:
         counts = np.zeros((self.num_envs, int(nbins), int(nbins)), dtype=np.uint32)
         self._chk(self.lib.pic_phase_histogram(self._h, int(nbins), float(vmin), float(vmax), _ptr(counts)))
         return counts
+
+    def phase_kl(self, feq, vmin, vmax):
+        """KL cost of every environment's phase-space density against feq [nbins][nbins] (pic_phase_kl) -> [num_envs]."""
+        f = np.ascontiguousarray(np.asarray(feq, dtype=np.float64))
+        if f.ndim != 2 or f.shape[0] != f.shape[1]:
+            raise ValueError("feq must be [nbins, nbins]")
+        kl = np.empty(self.num_envs)
+        self._chk(self.lib.pic_phase_kl(self._h, int(f.shape[0]), float(vmin), float(vmax), _ptr(f), _ptr(kl)))
+        return kl
 
     def stream_probe(self, repeats=10):
         g = C.c_double()

@@ -121,47 +121,37 @@ __global__ __launch_bounds__(BLOCK) void record_energies_kernel(const double* __
   slot[2 * nenv + e] = PEr[e];
 }
 
-// E_field.compute_E (src/control/actuator.py:54-63) for every environment:
-// E_ext[e][j] = sum_m basis_cos[j][m] a[e][m] + sum_m basis_sin[j][m] a[e][M+m].  The basis tables come from the
-// host mirror (they carry the reference's linspace(0, L, Ng) mesh, actuator.py:13).
-__global__ __launch_bounds__(BLOCK) void actuator_kernel(const double* __restrict__ bc, const double* __restrict__ bs,
-                                                         const double* __restrict__ act, double* __restrict__ ext,
-                                                         int Ng, int M) {
-  const int env = blockIdx.y;
+// Twiddle table of the Fourier modes: tw[m-1][j] = cos(2 pi m j / Ng), tw[rows + m-1][j] = sin(2 pi m j / Ng), m = 1..rows.
+// The angle is reduced exactly in integers before the trig call.
+__global__ __launch_bounds__(BLOCK) void twiddle_kernel(double* __restrict__ tw, int Ng, int rows) {
+  const int m = blockIdx.y + 1;
   const int j = blockIdx.x * BLOCK + threadIdx.x;
   if (j >= Ng) return;
-  const double* a = act + (size_t)env * 2 * M;
-  double c = 0.0, s = 0.0;
-  for (int m = 0; m < M; ++m) c += bc[(size_t)j * M + m] * a[m];
-  for (int m = 0; m < M; ++m) s += bs[(size_t)j * M + m] * a[M + m];
-  ext[(size_t)env * Ng + j] = c + s;
+  const long long r = ((long long)m * j) % Ng;
+  double sn, cs;
+  sincospi(2.0 * (double)r / (double)Ng, &sn, &cs);
+  tw[(size_t)(m - 1) * Ng + j] = cs;
+  tw[((size_t)rows + m - 1) * Ng + j] = sn;
 }
 
 // compute_E_k_spectrum rows 1..M (src/interpret/spectrum.py:16): Ek[m] = fft(E_mesh)[m] / Ng * 2.
-__global__ __launch_bounds__(BLOCK) void modes_kernel(const double* __restrict__ E_mesh, double* __restrict__ re,
-                                                      double* __restrict__ im, int Ng, int M) {
-  __shared__ double wr[WAVES], wi[WAVES];
-  const int env = blockIdx.y, m = blockIdx.x + 1;
-  double sr = 0.0, si = 0.0;
-  for (int j = threadIdx.x; j < Ng; j += BLOCK) {
-    // angle = 2 pi m j / Ng, reduced exactly in integers before the trig call
-    const long long r = ((long long)m * j) % Ng;
-    double sn, cs;
-    sincospi(2.0 * (double)r / (double)Ng, &sn, &cs);
-    const double e = E_mesh[(size_t)env * Ng + j];
-    sr += e * cs;
-    si -= e * sn;
-  }
-  sr = wave_sum(sr);
-  si = wave_sum(si);
-  if ((threadIdx.x & 63) == 0) { wr[threadIdx.x >> 6] = sr; wi[threadIdx.x >> 6] = si; }
-  __syncthreads();
+__global__ __launch_bounds__(BLOCK) void modes_kernel(const double* __restrict__ E_mesh, const double* __restrict__ tw, int rows,
+                                                      double* __restrict__ re, double* __restrict__ im, int Ng, int M) {
+  __shared__ double ws[2 * WAVES];
+  const int env = blockIdx.y, m = blockIdx.x;
+  double a, b;
+  mesh_mode<WAVES>(E_mesh + (size_t)env * Ng, tw + (size_t)m * Ng, tw + ((size_t)rows + m) * Ng, Ng, ws, a, b);
   if (threadIdx.x == 0) {
-    double a = 0.0, b = 0.0;
-    for (int w = 0; w < WAVES; ++w) { a += wr[w]; b += wi[w]; }
-    re[(size_t)env * M + (m - 1)] = a / Ng * 2.0;
-    im[(size_t)env * M + (m - 1)] = b / Ng * 2.0;
+    re[(size_t)env * M + m] = a;
+    im[(size_t)env * M + m] = b;
   }
+}
+
+// The feedback law's action from the mesh field as it stands (first step of a pic_step_feedback call on the streaming
+// schedule; later steps: the post-step solve computes it, pic_device.h: solve_block).
+__global__ __launch_bounds__(BLOCK) void feedback_kernel(const double* __restrict__ E_mesh, Feedback fb, int Ng) {
+  __shared__ double ws[2 * WAVES];
+  feedback_action<WAVES>(E_mesh + (size_t)blockIdx.x * Ng, fb, blockIdx.x, Ng, ws, nullptr);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -251,6 +241,22 @@ __global__ __launch_bounds__(BLOCK) void phase_hist_kernel(const typename P::X* 
     const int iv = hist_bin((double)v[(size_t)env * ld + i], vmin, vmax, sv, nb);
     if (ix >= 0 && iv >= 0) atomicAdd(&c[(size_t)ix * nb + iv], 1u);
   }
+}
+
+// KL cost of the phase-space density against a target (src/control/objective.py:16-18, Reward.compute_kl_divergence,
+// src/control/rl/reward.py:43-46): sum_ij rel_entr(f_ij, feq_ij + 1e-12) dx dv with f = counts n0 / dx / dv / N
+// (objective.py:12) and rel_entr(a, b) = a log(a / b) for a > 0, 0 for a = 0.  One workgroup per environment.
+__global__ __launch_bounds__(BLOCK) void phase_kl_kernel(const unsigned* __restrict__ counts, const double* __restrict__ feq,
+                                                         double* __restrict__ kl, int nb2, double norm, double dxdv) {
+  __shared__ double ws[WAVES];
+  const unsigned* c = counts + (size_t)blockIdx.x * nb2;
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < nb2; i += BLOCK) {
+    const double f = (double)c[i] * norm;
+    if (f > 0.0) acc += f * log(f / (feq[i] + 1e-12));
+  }
+  const double t = block_sum<WAVES>(acc, ws);
+  if (threadIdx.x == 0) kl[blockIdx.x] = t * dxdv;
 }
 
 // Streaming ceiling of this box for the sweeps' access shape: read two arrays, write two arrays, 16 B

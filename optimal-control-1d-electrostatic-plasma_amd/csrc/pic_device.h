@@ -13,6 +13,36 @@
 
 namespace {
 
+// Timeline hooks.  The product build defines nothing here and no stamp executes in libpicstep.so; the diagnostic build
+// profiles/timeline/picstep_timeline.hip defines PIC_STAMP(slot) (shader clock of thread 0 of the workgroup into a
+// buffer of its own) and PIC_STAMP_LOADS(slot) (the same after the wave's outstanding vector-memory operations).
+#ifndef PIC_STAMP
+#define PIC_STAMP(slot) ((void)0)
+#define PIC_STAMP_LOADS(slot) ((void)0)
+#endif
+
+constexpr int kMaxFeedbackModes = 16;   // modes of the on-device feedback law (pic_step_feedback)
+
+// A kernel argument read from the kernel-argument segment at the point of use.  By-value arguments are loaded into scalar
+// registers at the kernel's entry and held until their last use; the rarely used ones (a riding solve's outputs, the control
+// inputs of a step) then cost the particle loops scalar registers -- a wave of occupancy in the sweeps, spills in the
+// resident kernel.  offset: byte offset of the value in the argument list (arguments lie in declaration order, each at its
+// natural alignment, like the members of a struct).
+template <typename T>
+__device__ __forceinline__ T kernarg_at(size_t offset) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  using KP = const __attribute__((address_space(4))) char*;
+  KP ka = (KP)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(ka));                       // opaque: the loads below stay where they are written
+  T out;
+  __builtin_memcpy(&out, (const __attribute__((address_space(4))) T*)(ka + offset), sizeof(T));
+  return out;
+#else
+  (void)offset;
+  return T{};                                        // (host pass of the single-source compilation: never executed)
+#endif
+}
+
 constexpr int BLOCK = 512;          // sweep workgroup: 8 waves of 64 (512 beat 256 by 2.7 % and 128 by 11 % at config 2)
 constexpr int WAVES = BLOCK / 64;
 
@@ -30,6 +60,26 @@ enum Stage : int {
 // the same whatever the launch geometry and however the adds of different workgroups interleave.
 using acc_t = long long;
 
+// An accumulator row is kept as S sub-rows [S][env][Ng] whose integer sum is the deposit.  With one sub-row every workgroup of
+// an environment adds to the same 8 Ng bytes, and the memory-side atomic units serialise them: with ONE environment of 1e6
+// particles (245 workgroups) the flush took 2-5 us of a 13 us sweep and held up the kernel boundary behind it
+// (profiles/r3_timeline.md).  Few-environment handles therefore spread a row over several sub-rows; integer sums make the
+// result independent of S bit for bit.
+__device__ __forceinline__ acc_t acc_row_sum(const acc_t* __restrict__ row, int j, int S, long long sub) {
+  const acc_t* p = row + j;
+  acc_t t = 0;
+  int s = 0;
+  for (; s + 4 <= S; s += 4) {                       // four loads in flight at a time
+    const acc_t r0 = p[0]; p += sub;
+    const acc_t r1 = p[0]; p += sub;
+    const acc_t r2 = p[0]; p += sub;
+    const acc_t r3 = p[0]; p += sub;
+    t += (r0 + r1) + (r2 + r3);
+  }
+  for (; s < S; ++s) { t += p[0]; p += sub; }
+  return t;
+}
+
 struct SweepArgs {
   long long N;        // particles per env
   long long ld;       // leading dimension of x, v
@@ -39,6 +89,8 @@ struct SweepArgs {
   int R;              // LDS mesh replicas per workgroup (a power of two; the host uses 1: profiles/experiments_r2.md 17)
   int reverse;        // walk environments and chunks from the far end (alternates sweep to sweep)
   int fg;             // fractional bits of the fixed-point accumulators
+  int S;              // sub-rows of an accumulator row: workgroup b adds its mesh into sub-row b % S, readers sum the S sub-rows
+  long long sub;      // elements from one sub-row to the next (num_envs * Ng)
   double magic;       // 1.5 * 2^(52 - fg): (w + magic) holds round(w 2^fg) in its low mantissa bits
   double L, dx, rdx, dt;   // rdx = 1/dx (float particles: 1/(float)dx)
   double c_prev, c_cur, d_cur, c_next;
@@ -49,13 +101,36 @@ struct SweepArgs {
 
 struct SolveArgs {
   long long N;
+  long long sub;       // elements between the sub-rows of an accumulator row
   int Ng;
   int nblk;
   int fg;
+  int S;               // sub-rows of the accumulator row read (1 for a plain row)
   double L, dx, n0;
   double scale;        // n0 * L / N / dx, evaluated left to right as interpolate.py:18
   double N_over_L;
 };
+
+// How the external field of a step's force evaluations is obtained (util.py:102-103 adds it to E_mesh): given on the mesh,
+// or built from actuator coefficients inside the field phase, E_ext = basis_cos @ a[:M] + basis_sin @ a[M:]
+// (src/control/actuator.py:54-63) -- no actuator launch and no mesh-sized array per step.  Pointers are those of environment 0
+// (and of the first step of the call).
+struct Control {
+  const double* ext;     // [env][Ng], or null
+  const double* act;     // [env][2M] coefficients (cos half, then sin half), or null; wins over ext
+  const double* basis;   // [2][Ng][M] cos | sin tables of the host mirror (they carry the reference's linspace(0, L, Ng) mesh)
+  int M;
+};
+
+// E_field.compute_E at mesh node j (actuator.py:54-63): both products summed over m in order, then added -- the operation
+// order every caller of the device actuator has had since round 1 (results are compared bit for bit across schedules).
+__device__ __forceinline__ double actuator_field(const double* __restrict__ bc, const double* __restrict__ bs,
+                                                 const double* __restrict__ a, int j, int M) {
+  double c = 0.0, s = 0.0;
+  for (int m = 0; m < M; ++m) c += bc[(size_t)j * M + m] * a[m];
+  for (int m = 0; m < M; ++m) s += bs[(size_t)j * M + m] * a[M + m];
+  return c + s;
+}
 
 // ---------------------------------------------------------------------------------------------
 // Particle formats.  X / V: storage types of position and velocity; W: type locate, the shape weights,
@@ -73,6 +148,33 @@ typedef unsigned pic_v4u __attribute__((ext_vector_type(4)));
 struct PosF64 { using X = double;   using V = double; using W = double; using XV = pic_v2d; using VV = pic_v2d; static constexpr int VEC = 2; static constexpr bool kFixed = false; };
 struct PosF32 { using X = float;    using V = float;  using W = float;  using XV = pic_v4f; using VV = pic_v4f; static constexpr int VEC = 4; static constexpr bool kFixed = false; };
 struct PosU32 { using X = unsigned; using V = float;  using W = float;  using XV = pic_v4u; using VV = pic_v4f; static constexpr int VEC = 4; static constexpr bool kFixed = true; };
+
+// The 16-byte accesses of the particle streams.
+// Stores are WRITE-THROUGH (`sc1`): the bytes go to the memory side at once and the line is dropped from the XCD's L2.  A plain
+// store leaves its line dirty in L2 until the end of the kernel, and the write-back of what a sweep has left there sits between
+// it and the next one on the stream: with ONE environment of 1e6 particles (16 MB written per sweep, all of it still in the
+// 32 MB of L2 at the end) that was 5-7 us per kernel boundary, 47 -> 31 us per step; 2 / 4 / 12 environments 50.8 -> 45 /
+// 77.6 -> 74 / 194 -> 190.5, config 2 989 -> 974 (profiles/experiments_r3.md 2; `nt` stores keep the line and gain nothing).
+// Nothing re-reads a particle in the sweep that stored it, and the next sweep runs on other CUs anyway: no reuse is given up.
+// HIP has no 16-byte store with a scope; the buffer-store builtin takes the cache policy as an operand (16 = sc1) and, unlike
+// inline assembly, leaves hazards and vmcnt to the compiler (an `asm` store was tried first: the compiler then scheduled a
+// VALU write of the store's data registers right behind it, which gfx950 does not interlock -- tests/ caught it).
+template <typename VT>
+__device__ __forceinline__ VT stream_load(const VT* p) { return *p; }
+
+// base: wave-uniform (a workgroup's chunk of one array, < 2 GiB: pic_create sees to it); off: this lane's byte offset from it
+struct StreamOut {
+  __amdgpu_buffer_rsrc_t rsrc;
+  __device__ explicit StreamOut(void* base) : rsrc(__builtin_amdgcn_make_buffer_rsrc(base, 0, 0x7fffffff, 0x00020000)) {}
+  template <typename VT>
+  __device__ __forceinline__ void store(int off, VT v) const {
+    static_assert(sizeof(VT) == 16, "particle tiles are 16 bytes per lane");
+    typedef unsigned pic_v4raw __attribute__((ext_vector_type(4)));
+    pic_v4raw w;
+    __builtin_memcpy(&w, &v, 16);
+    __builtin_amdgcn_raw_buffer_store_b128(w, rsrc, off, 0, 16);
+  }
+};
 
 // loop-invariant scalars of a sweep in the format's arithmetic type
 template <typename P>
@@ -352,6 +454,53 @@ __device__ __forceinline__ void block_sum2(double a, double b, double* ws, doubl
   __syncthreads();
 }
 
+// Fourier mode m of a mesh row E [Ng] by a workgroup of NW waves: fft(E)[m] / Ng * 2 (src/interpret/spectrum.py:16).
+// twc / tws: cos and sin of 2 pi m j / Ng, j = 0..Ng-1 (twiddle_kernel, pic_aux.h).  Thread t takes the nodes t + k 64 NW; E may
+// be global memory the same threads wrote a moment ago (each reads back its own nodes only).  ws: 2 NW doubles of LDS.
+template <int NW>
+__device__ __forceinline__ void mesh_mode(const double* __restrict__ E, const double* __restrict__ twc,
+                                          const double* __restrict__ tws, int Ng, double* __restrict__ ws, double& re,
+                                          double& im) {
+  double sr = 0.0, si = 0.0;
+  int t0 = threadIdx.x;
+  asm volatile("" : "+v"(t0));      // (keeps the per-lane addresses below from being hoisted out of a caller's step loop into registers held across it)
+  for (int j = t0; j < Ng; j += NW * 64) {
+    const double e = E[j];
+    sr += e * twc[j];
+    si -= e * tws[j];
+  }
+  double a, b;
+  block_sum2<NW>(sr, si, ws, a, b);
+  re = a / Ng * 2.0;
+  im = b / Ng * 2.0;
+}
+
+// Linear feedback law of run_feedback.py:133-135 (and the behaviour-cloning action of src/control/rl/ddpg.py:369-371): the
+// actuator coefficients of the next step are (-Re, +Im) of modes 1..M of the mesh field the last step left.
+struct Feedback {
+  const double* tw;      // [2][rows][Ng] cos | sin twiddles, row m-1 = mode m
+  int rows;
+  int M;                 // 0 = no feedback
+  double* act_out;       // [env][2M] the action computed (read by the next force evaluations), or null
+  double* act_hist;      // [env][2M] of the step the action is for, in a per-step record, or null
+};
+
+// a_lds (2M doubles of LDS, or null) also receives the action; the caller puts a barrier before reading it
+template <int NW>
+__device__ __forceinline__ void feedback_action(const double* __restrict__ E, const Feedback& fb, int env, int Ng,
+                                                double* __restrict__ ws, double* __restrict__ a_lds) {
+  for (int m = 0; m < fb.M; ++m) {
+    double re, im;
+    mesh_mode<NW>(E, fb.tw + (size_t)m * Ng, fb.tw + ((size_t)fb.rows + m) * Ng, Ng, ws, re, im);
+    if (threadIdx.x == 0) {
+      const double c = -re, s = im;
+      if (a_lds) { a_lds[m] = c; a_lds[fb.M + m] = s; }
+      if (fb.act_out) { fb.act_out[(size_t)env * 2 * fb.M + m] = c; fb.act_out[(size_t)env * 2 * fb.M + fb.M + m] = s; }
+      if (fb.act_hist) { fb.act_hist[(size_t)env * 2 * fb.M + m] = c; fb.act_hist[(size_t)env * 2 * fb.M + fb.M + m] = s; }
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Periodic Poisson solve of one environment, in LDS.
 // Replaces Gaussian_Elimination_Periodic + the dense grad matvec (src/env/solve.py:27-53, src/env/util.py:99-103,
@@ -406,6 +555,7 @@ struct SolveOut {
   double *KE, *PE, *PEr;   // [env]
   double* hist;            // [3][num_envs] KE, PE, PE_reward of this solve once more (one step's entry of an energy history), or null
   int num_envs;
+  Feedback fb;             // fb.M > 0: the feedback action from the E just solved (needs E != null)
 };
 
 // From sb = b = n - n0 (filled by the caller, barrier included) to E (+ E_ext), zero-mean phi, PE = 0.5 sum(E^2) dx N/L
@@ -445,6 +595,7 @@ __device__ __forceinline__ void solve_block(const SolveOut& o, int env, int Ng, 
       o.hist[2 * (size_t)o.num_envs + env] = pe;
     }
   }
+  if (o.fb.M > 0) feedback_action<NW>(o.E + row, o.fb, env, Ng, ws, nullptr);   // (block_sum2 ended with a barrier: ws is free)
 }
 
 }  // namespace

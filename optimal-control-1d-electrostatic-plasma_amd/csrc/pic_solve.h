@@ -12,7 +12,7 @@ constexpr int SBLOCK = BLOCK;        // 8 waves, as the sweeps and the resident 
 constexpr int SWAVES = SBLOCK / 64;  // kinetic-energy partials are then grouped the same way in all three
 
 struct SolveIO {
-  const acc_t* acc;        // [env][Ng] deposit (weight sums, 2^-fg units), or null when rhs is given
+  const acc_t* acc;        // [S][env][Ng] deposit (weight sums, 2^-fg units, S sub-rows), or null when rhs is given
   const double* rhs;       // [env][Ng] right-hand side taken as it is (pic_solve_poisson)
   const double* ke_part;   // [env][nblk] or null
   double* n;               // [env][Ng] density out, or null
@@ -21,8 +21,9 @@ struct SolveIO {
 
 // Density from the accumulator row (or the given right-hand side) of environment `env`, then solve_block.  Called by a whole
 // workgroup of SBLOCK threads; smem: 2 Ng doubles of LDS, ws: 2 SWAVES doubles, slot: 2 doubles.
-__device__ __forceinline__ void solve_environment(const SolveIO& io, int env, int Ng, int nblk, int fg, double scale, double n0,
-                                                  double dx, double N_over_L, unsigned char* smem, double* ws, double* slot) {
+__device__ __forceinline__ void solve_environment(const SolveIO& io, int env, int Ng, int nblk, int fg, int S, long long sub,
+                                                  double scale, double n0, double dx, double N_over_L, unsigned char* smem,
+                                                  double* ws, double* slot) {
   double* sb = reinterpret_cast<double*>(smem);       // b, then G_{j+1/2}
   double* se = sb + Ng;                               // phi
   const int tid = threadIdx.x;
@@ -31,7 +32,7 @@ __device__ __forceinline__ void solve_environment(const SolveIO& io, int env, in
   if (io.acc) {
     const double unit = ldexp(1.0, -fg);
     for (int j = tid; j < Ng; j += SBLOCK) {
-      const double nj = ((double)io.acc[row + j] * unit) * scale;
+      const double nj = ((double)acc_row_sum(io.acc + row, j, S, sub) * unit) * scale;
       if (io.n) io.n[row + j] = nj;
       sb[j] = nj - n0;
     }
@@ -51,7 +52,7 @@ __global__ __launch_bounds__(SBLOCK) void field_solve_kernel(SolveIO io, SolveAr
   extern __shared__ __align__(16) unsigned char smem_raw[];
   __shared__ double ws[2 * SWAVES];
   __shared__ double slot[2];
-  solve_environment(io, blockIdx.x, a.Ng, a.nblk, a.fg, a.scale, a.n0, a.dx, a.N_over_L, smem_raw, ws, slot);
+  solve_environment(io, blockIdx.x, a.Ng, a.nblk, a.fg, a.S, a.sub, a.scale, a.n0, a.dx, a.N_over_L, smem_raw, ws, slot);
 }
 
 }  // namespace

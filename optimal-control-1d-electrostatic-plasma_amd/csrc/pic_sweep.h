@@ -6,19 +6,28 @@
 
 namespace {
 
-// Field tile of a sweep workgroup, computed in its own prologue from the accumulator row [Ng] the previous sweep
+// Field tile of a sweep workgroup, computed in its own prologue from the accumulator row the previous sweep
 // filled: density -> b = n - n0 -> G = dx cumsum(b) - mean -> E_j = -(G_{j+1/2} + G_{j-1/2})/2 (+ E_ext).
 // Every workgroup of an environment repeats the solve (2 KB of input at Ng = 256, read through L2); in exchange a
 // step has no field-solve launch between its sweeps.  sb: Ng doubles of LDS scratch.
+// ctl (pointers of THIS environment): the external field on the mesh, or the actuator coefficients it is built from here
+// (xt: Ng doubles of LDS scratch for it) -- a controlled step has no actuator launch either.
 template <typename T, int OFF>
-__device__ __forceinline__ void prologue_field(const acc_t* __restrict__ acc_in, const double* __restrict__ ext, int Ng,
-                                               double unit, double scale, double n0, double dx,
-                                               double* __restrict__ sb, double* __restrict__ slot, T* __restrict__ Es) {
+__device__ __forceinline__ void prologue_field(const acc_t* __restrict__ acc_in, int S, long long sub, const Control& ctl,
+                                               int Ng, double unit, double scale, double n0, double dx,
+                                               double* __restrict__ sb, double* __restrict__ xt, double* __restrict__ slot,
+                                               T* __restrict__ Es) {
   const int tid = threadIdx.x;
-  for (int j = tid; j < Ng; j += BLOCK) sb[j] = ((double)acc_in[j] * unit) * scale - n0;   // interpolate.py:16-18, pic.py:116
+  for (int j = tid; j < Ng; j += BLOCK)
+    sb[j] = ((double)acc_row_sum(acc_in, j, S, sub) * unit) * scale - n0;                   // interpolate.py:16-18, pic.py:116
+  if (ctl.act)
+    for (int j = tid; j < Ng; j += BLOCK)
+      xt[j] = actuator_field(ctl.basis, ctl.basis + (size_t)Ng * ctl.M, ctl.act, j, ctl.M);  // actuator.py:54-63
   __syncthreads();
+  PIC_STAMP(3);
   scan_fields(sb, nullptr, Ng, dx, slot);
   __syncthreads();
+  PIC_STAMP(4);
   const double gmean = slot[0];
   for (int i = tid; i < Ng + 2; i += BLOCK) {
     int node = i - OFF;
@@ -26,10 +35,12 @@ __device__ __forceinline__ void prologue_field(const acc_t* __restrict__ acc_in,
     const double gp = sb[node] - gmean;
     const double gm = sb[node == 0 ? Ng - 1 : node - 1] - gmean;
     double E = -0.5 * (gp + gm);
-    if (ext) E += ext[node];                                                              // util.py:102-103
+    if (ctl.act) E += xt[node];                                                           // util.py:102-103
+    else if (ctl.ext) E += ctl.ext[node];
     Es[i] = (T)E;
   }
   __syncthreads();
+  PIC_STAMP(5);
 }
 
 // One particle through one sub-stage.  Stages D / REFRESH also deposit the NEXT step's first drift
@@ -116,13 +127,16 @@ __device__ __forceinline__ void flush_mesh(const A* __restrict__ acc_all, int R,
   }
 }
 
+constexpr size_t kSweepStaticLds = (2 * WAVES + 2) * sizeof(double);     // sweep_kernel's static __shared__ arrays
+
 // what a sweep reads its field from, where its deposits go, which retired accumulator rows it clears
 struct SweepIO {
-  const acc_t* acc_in;     // [env][Ng] deposit the field of this sweep's gather is solved from (gather stages)
-  const double* ext;       // [env][Ng] external field added to it, or null
-  acc_t* acc_out;          // [env][Ng] receives this sweep's deposit (zero on entry)
-  acc_t* acc_out2;         // [env][Ng] receives the next step's q1 deposit (dual stages)
-  acc_t* zero0;            // [env][Ng] accumulators no kernel reads any more: cleared for a later sweep
+  // accumulator rows are [S][env][Ng] (S sub-rows, SweepArgs::S; pic_device.h: acc_row_sum)
+  const acc_t* acc_in;     // deposit the field of this sweep's gather is solved from (gather stages)
+  Control ctl;             // external field of the force evaluation: on the mesh or as actuator coefficients (environment 0's pointers)
+  acc_t* acc_out;          // receives this sweep's deposit (zero on entry)
+  acc_t* acc_out2;         // receives the next step's q1 deposit (dual stages)
+  acc_t* zero0;            // accumulators no kernel reads any more: cleared for a later sweep
   acc_t* zero1;
   double* ke_part;         // [env][nblk] sum of p^2 per workgroup (dual stages)
   unsigned long long* bad; // [1] count of non-finite / unrepresentable positions
@@ -157,9 +171,15 @@ __global__ __launch_bounds__(BLOCK) void sweep_kernel(typename P::X* __restrict_
   T* Es = reinterpret_cast<T*>(smem_raw + (size_t)2 * a.R * stride * sizeof(A));
   __shared__ double red[2 * WAVES];
   __shared__ double slot[2];       // mean of the prologue solve's gradient (16 B: keeps the dynamic LDS base aligned)
+  static_assert(sizeof(red) + sizeof(slot) == kSweepStaticLds, "pic_create adds the static LDS to the dynamic part it sizes");
+  PIC_STAMP(0);
 
   if (STAGE == ST_B && blockIdx.x == (unsigned)a.nblk) {      // the extra workgroup of its environment (host: only with io.post.acc)
-    solve_environment(io.post, blockIdx.y, Ng, a.nblk, a.fg, a.scale, a.n0, a.dx, a.N_over_L, smem_raw, red, slot);
+    // its arguments are read from the kernel-argument segment here, by this workgroup alone: held in scalar registers from the
+    // kernel's entry on they cost every other workgroup of the sweep a wave of occupancy (pic_device.h: kernarg_at)
+    SolveIO post = kernarg_at<SolveIO>(2 * sizeof(void*) + offsetof(SweepIO, post));   // x, v, io, a
+    post.out.fb = Feedback{};                                  // (the feedback law's solves are launches of their own)
+    solve_environment(post, blockIdx.y, Ng, a.nblk, a.fg, a.S, a.sub, a.scale, a.n0, a.dx, a.N_over_L, smem_raw, red, slot);
     return;
   }
 
@@ -182,19 +202,27 @@ __global__ __launch_bounds__(BLOCK) void sweep_kernel(typename P::X* __restrict_
   XV xv = {};
   VV vv = {};
   if (i + VEC <= end) {
-    xv = *reinterpret_cast<const XV*>(xe + i);
-    if (kReadV) vv = *reinterpret_cast<const VV*>(ve + i);
+    xv = stream_load(reinterpret_cast<const XV*>(xe + i));
+    if (kReadV) vv = stream_load(reinterpret_cast<const VV*>(ve + i));
   }
+  PIC_STAMP(2);
 
-  if (kGather)
-    prologue_field<T, OFF>(io.acc_in + (size_t)env * Ng, io.ext ? io.ext + (size_t)env * Ng : nullptr, Ng,
-                           ldexp(1.0, -a.fg), a.scale, a.n0, a.dx, reinterpret_cast<double*>(smem_raw), slot, Es);
+  if (kGather) {
+    Control ctl = io.ctl;
+    if (ctl.ext) ctl.ext += (size_t)env * Ng;
+    if (ctl.act) ctl.act += (size_t)env * 2 * ctl.M;
+    // LDS scratch of the prologue: b / G in the first mesh's place, the actuator field in the second's
+    prologue_field<T, OFF>(io.acc_in + (size_t)env * Ng, a.S, a.sub, ctl, Ng, ldexp(1.0, -a.fg), a.scale, a.n0, a.dx,
+                           reinterpret_cast<double*>(smem_raw), reinterpret_cast<double*>(acc2_all), slot, Es);
+  }
   for (int c = tid; c < nacc; c += BLOCK) acc_all[c] = A{};
-  if (blk == 0) {       // one workgroup per environment clears the retired accumulator rows
-    if (io.zero0) for (int c = tid; c < Ng; c += BLOCK) io.zero0[(size_t)env * Ng + c] = 0;
-    if (io.zero1) for (int c = tid; c < Ng; c += BLOCK) io.zero1[(size_t)env * Ng + c] = 0;
+  if (blk < a.S) {      // workgroup s of an environment clears sub-row s of the retired accumulator rows
+    const size_t z = (size_t)blk * a.sub + (size_t)env * Ng;
+    if (io.zero0) for (int c = tid; c < Ng; c += BLOCK) io.zero0[z + c] = 0;
+    if (io.zero1) for (int c = tid; c < Ng; c += BLOCK) io.zero1[z + c] = 0;
   }
   __syncthreads();
+  PIC_STAMP(6);
 
   const int rep = (tid >> 6) & (a.R - 1);
   A* acc = acc_all + (size_t)rep * stride;
@@ -203,7 +231,10 @@ __global__ __launch_bounds__(BLOCK) void sweep_kernel(typename P::X* __restrict_
 
   double ke = 0.0;
   unsigned bad = 0u;
+  [[maybe_unused]] int tile = 0;
+  const StreamOut xout(xe + begin), vout(ve + begin);
   while (i + VEC <= end) {
+    PIC_STAMP_LOADS(8 + 2 * tile);
     typename P::X* xs = reinterpret_cast<typename P::X*>(&xv);
     typename P::V* vs = reinterpret_cast<typename P::V*>(&vv);
 #pragma unroll
@@ -213,13 +244,15 @@ __global__ __launch_bounds__(BLOCK) void sweep_kernel(typename P::X* __restrict_
       if (kReadV) vs[c] = pv;
     }
     if (kStore) {
-      *reinterpret_cast<XV*>(xe + i) = xv;
-      if (kStoreV) *reinterpret_cast<VV*>(ve + i) = vv;
+      xout.store((int)((i - begin) * (long long)sizeof(typename P::X)), xv);
+      if (kStoreV) vout.store((int)((i - begin) * (long long)sizeof(typename P::V)), vv);
     }
+    PIC_STAMP(9 + 2 * tile);
+    ++tile;
     i += step;
     if (i + VEC <= end) {
-      xv = *reinterpret_cast<const XV*>(xe + i);
-      if (kReadV) vv = *reinterpret_cast<const VV*>(ve + i);
+      xv = stream_load(reinterpret_cast<const XV*>(xe + i));
+      if (kReadV) vv = stream_load(reinterpret_cast<const VV*>(ve + i));
     }
   }
   for (long long c = i; c < end; ++c) {       // ragged tail (fewer than VEC particles left for this lane)
@@ -232,9 +265,12 @@ __global__ __launch_bounds__(BLOCK) void sweep_kernel(typename P::X* __restrict_
     }
   }
   __syncthreads();
+  PIC_STAMP(24);
 
-  flush_mesh<A, SHAPE>(acc_all, a.R, stride, Ng, a.fg, io.acc_out + (size_t)env * Ng);
-  if (kDual) flush_mesh<A, SHAPE>(acc2_all, a.R, stride, Ng, a.fg, io.acc_out2 + (size_t)env * Ng);
+  const size_t sub_row = (size_t)(blk % a.S) * a.sub + (size_t)env * Ng;
+  flush_mesh<A, SHAPE>(acc_all, a.R, stride, Ng, a.fg, io.acc_out + sub_row);
+  if (kDual) flush_mesh<A, SHAPE>(acc2_all, a.R, stride, Ng, a.fg, io.acc_out2 + sub_row);
+  PIC_STAMP(25);
 
   if (kDual) {
     double w = wave_sum(ke);
@@ -247,6 +283,7 @@ __global__ __launch_bounds__(BLOCK) void sweep_kernel(typename P::X* __restrict_
     }
   }
   if (bad) atomicAdd(io.bad, (unsigned long long)bad);
+  PIC_STAMP_LOADS(26);
 }
 
 }  // namespace

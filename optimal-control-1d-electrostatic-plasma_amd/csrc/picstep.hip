@@ -36,6 +36,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -72,6 +73,7 @@ struct pic_handle {
   int nblk = 0;
   int R = 1;
   int fg = 42;             // fractional bits of the fixed-point accumulators
+  int S = 1;               // sub-rows per accumulator row (pic_device.h: acc_row_sum)
   double magic = 0;
   size_t sweep_lds = 0, solve_lds = 0;
   // resident schedule (pic_resident.h): one workgroup of res_nw waves holds an environment, res_ppt particles per lane
@@ -89,6 +91,7 @@ struct pic_handle {
   double* post_hist_row = nullptr;    // the same for the solve that post_slot stands for
   int place_tried = 1;                // (x, v) placements pic_create timed (alloc_particles)
   double place_gbs[2] = {0.0, 0.0};   // streaming rate of the one kept and of the slowest one, GB/s
+  double place_seconds = 0.0;         // wall time the placement search took inside pic_create
   void* x = nullptr;
   void* v = nullptr;
   void* scratch = nullptr;        // [env][ld] positions of a probe (eval_field / compute_E)
@@ -107,10 +110,17 @@ struct pic_handle {
   double* phi = nullptr;
   double* ext = nullptr;          // device copy of a host E_ext / output of the device actuator
   double* basis = nullptr;        // [2][Ng][M] actuator tables (cos, sin)
-  double* act = nullptr;          // [env][2M] actions
+  double* act = nullptr;          // [env][2M] actions: device copy of a host action / the feedback law's current action
   double* modes = nullptr;        // [2][env][M] Fourier modes (re, im)
   int act_modes = 0;
   int modes_cap = 0;
+  double* tw = nullptr;           // [2][tw_rows][Ng] twiddles of modes 1..tw_rows (pic_aux.h: twiddle_kernel)
+  int tw_rows = 0;
+  void* traj = nullptr;           // device copy of a host trajectory of actions or fields (pic_step_*_traj), grown on demand
+  size_t traj_bytes = 0;
+  unsigned long long* res_q1 = nullptr;   // resident schedule: [env][R (Ng + 2)] LDS mesh of the next step's q1 deposit, launch to launch
+  bool res_q1_valid = false;
+  Feedback fb{};                  // feedback outputs wanted from the NEXT post-step solve of the streaming schedule (fb.M = 0: none)
   double* aux_n = nullptr;        // probe outputs
   double* aux_E = nullptr;
   double* aux_pe = nullptr;
@@ -163,14 +173,15 @@ void yoshida_coefficients(double (&c)[4], double (&d)[4]) {
 }
 
 // ---- accumulator ring -------------------------------------------------------------------------
-acc_t* ring_row(pic_handle* h, int slot) { return h->ring + (size_t)slot * h->cfg.num_envs * h->cfg.Ng; }
+size_t row_elems(const pic_handle* h) { return (size_t)h->S * h->cfg.num_envs * h->cfg.Ng; }       // one accumulator row: [S][env][Ng]
+acc_t* ring_row(pic_handle* h, int slot) { return h->ring + (size_t)slot * row_elems(h); }
 
 // a zeroed row for the deposit of the sweep about to be launched
 int ring_take_clean(pic_handle* h) {
   if (h->clean.empty()) {          // not reached by the step schedule (every sweep clears two retired rows)
     const int s = h->dirty.front();
     h->dirty.erase(h->dirty.begin());
-    hipMemsetAsync(ring_row(h, s), 0, (size_t)h->cfg.num_envs * h->cfg.Ng * sizeof(acc_t), h->stream);
+    hipMemsetAsync(ring_row(h, s), 0, row_elems(h) * sizeof(acc_t), h->stream);
     return s;
   }
   const int s = h->clean.back();
@@ -255,11 +266,12 @@ void prof_end(pic_handle* h) {
 // out / out2: rows (or the probe accumulator) receiving the deposits.  The sweep also clears up to two
 // retired ring rows for later use.
 void launch_sweep(pic_handle* h, int stage, void* x, void* v, double c_prev, double c_cur, double d_cur,
-                  int in_slot, const double* ext, acc_t* out, acc_t* out2, int post_slot = -1) {
+                  int in_slot, const Control& ctl, acc_t* out, acc_t* out2, int post_slot = -1) {
   SweepArgs a;
   a.N = h->cfg.N; a.ld = h->ld; a.chunk = h->chunk; a.Ng = h->cfg.Ng; a.nblk = h->nblk; a.R = h->R;
   a.reverse = (stage <= ST_D) ? (h->sweep_parity ^= 1) : 0;
   a.fg = h->fg; a.magic = h->magic;
+  a.S = h->S; a.sub = (long long)h->cfg.num_envs * h->cfg.Ng;
   a.L = h->cfg.L; a.dx = h->dx; a.dt = h->cfg.dt;
   a.rdx = h->fmt == FMT_F64 ? 1.0 / h->dx : (double)(1.0f / (float)h->dx);
   a.c_prev = c_prev; a.c_cur = c_cur; a.d_cur = d_cur; a.c_next = h->cs[0];
@@ -268,7 +280,7 @@ void launch_sweep(pic_handle* h, int stage, void* x, void* v, double c_prev, dou
   a.N_over_L = (double)h->cfg.N / h->cfg.L;
   SweepIO io{};
   io.acc_in = in_slot >= 0 ? ring_row(h, in_slot) : nullptr;
-  io.ext = ext;
+  io.ctl = ctl;
   io.acc_out = out;
   io.acc_out2 = out2;
   int z[2] = {-1, -1};
@@ -327,8 +339,16 @@ void launch_resident_p(pic_handle* h, const ResidentIO& io, const SweepArgs& a) 
   else launch_resident_s<P, acc_t, PIC_CIC>(h, io, a);
 }
 
+// What drives the external field of the steps of one call (device pointers; see Control / Feedback in pic_device.h)
+struct StepControl {
+  Control ctl{};           // first step's field or action (environment 0)
+  long long ext_step = 0;  // elements between consecutive steps' fields / actions (0: held for the whole call)
+  long long act_step = 0;
+  Feedback fb{};           // fb.M > 0: feedback law; fb.act_hist = device [nsteps][env][2M] record of the actions, or null
+};
+
 // nsteps environment steps in one launch of the resident schedule; hist: device [nsteps][3][env] or null
-void launch_resident(pic_handle* h, const double* ext, int nsteps, double* hist, void* snap = nullptr) {
+void launch_resident(pic_handle* h, const StepControl& sc, int nsteps, double* hist, void* snap = nullptr) {
   SweepArgs a{};
   a.N = h->cfg.N; a.ld = h->ld; a.Ng = h->cfg.Ng; a.R = h->res_R;
   a.fg = h->fg; a.magic = h->magic;
@@ -338,10 +358,18 @@ void launch_resident(pic_handle* h, const double* ext, int nsteps, double* hist,
   a.to_units = 4294967296.0 / h->cfg.L;
   a.N_over_L = (double)h->cfg.N / h->cfg.L;
   ResidentIO io{};
-  io.ext = ext;
-  io.n = h->n; io.E = h->E_mesh; io.phi = h->phi; io.KE = h->KE; io.PE = h->PE; io.PEr = h->PEr;
-  io.hist = hist; io.snap = snap; io.bad = h->bad; io.nsteps = nsteps; io.num_envs = h->cfg.num_envs;
+  io.nsteps = nsteps; io.num_envs = h->cfg.num_envs;
   io.c1 = h->cs[0]; io.c2 = h->cs[1]; io.d1 = h->ds[1]; io.d2 = h->ds[2];
+  io.c.ctl = sc.ctl; io.c.ext_step = sc.ext_step; io.c.act_step = sc.act_step; io.c.fb = sc.fb;
+  io.o.n = h->n; io.o.E = h->E_mesh; io.o.phi = h->phi; io.o.KE = h->KE; io.o.PE = h->PE; io.o.PEr = h->PEr;
+  io.o.hist = hist;
+  io.e.snap = snap; io.e.bad = h->bad;
+  // the LDS mesh with the next step's q1 deposit travels from launch to launch (pic_invalidate and every reload drop it)
+  io.e.q1_in = h->res_q1_valid ? h->res_q1 : nullptr;
+  io.e.q1_out = h->res_q1;
+  h->res_q1_valid = true;
+  io.mode = (sc.ctl.ext || sc.ctl.act || sc.fb.M > 0 ? RM_EXT : 0) | (sc.ext_step || sc.act_step ? RM_PER_STEP : 0) |
+            (sc.fb.M > 0 ? RM_FEEDBACK : 0) | (snap ? RM_SNAP : 0);
   prof_begin(h, 6);
   if (h->fmt == FMT_F64) launch_resident_p<PosF64>(h, io, a);
   else if (h->fmt == FMT_F32) launch_resident_p<PosF32>(h, io, a);
@@ -353,6 +381,7 @@ void launch_solve(pic_handle* h, const SolveIO& io) {
   SolveArgs a;
   a.N = h->cfg.N; a.Ng = h->cfg.Ng; a.nblk = h->nblk; a.fg = h->fg; a.L = h->cfg.L; a.dx = h->dx; a.n0 = h->cfg.n0;
   a.scale = h->scale; a.N_over_L = (double)h->cfg.N / h->cfg.L;
+  a.S = io.acc ? h->S : 1; a.sub = (long long)h->cfg.num_envs * h->cfg.Ng;
   prof_begin(h, 4);
   hipLaunchKernelGGL(field_solve_kernel, dim3(h->cfg.num_envs), dim3(SBLOCK), h->solve_lds, h->stream, io, a);
   prof_end(h);
@@ -365,6 +394,7 @@ void launch_final_solve(pic_handle* h, int slot) {
   o.ke_part = h->ke_part; o.n = h->n; o.out.E = h->E_mesh; o.out.phi = h->phi;
   o.out.KE = h->KE; o.out.PE = h->PE; o.out.PEr = h->PEr;
   o.out.hist = h->hist_row; o.out.num_envs = h->cfg.num_envs;
+  o.out.fb = h->fb;
   launch_solve(h, o);
   ring_retire(h, slot);
 }
@@ -374,12 +404,13 @@ void drop_cached_deposits(pic_handle* h) {
   ring_retire(h, h->stage_slot);
   h->q_slot = h->stage_slot = -1;
   h->mid_stage = 0;
+  h->res_q1_valid = false;
 }
 
 int refresh_fields(pic_handle* h) {
   drop_cached_deposits(h);
   const int f = ring_take_clean(h), qn = ring_take_clean(h);
-  launch_sweep(h, ST_REFRESH, h->x, h->v, 0, 0, 0, -1, nullptr, ring_row(h, f), ring_row(h, qn));
+  launch_sweep(h, ST_REFRESH, h->x, h->v, 0, 0, 0, -1, Control{}, ring_row(h, f), ring_row(h, qn));
   launch_final_solve(h, f);
   HIPCHK(h, hipGetLastError());
   h->q_slot = qn;   // ST_REFRESH also deposited the next step's q1
@@ -494,21 +525,27 @@ const char* pic_last_error(pic_handle* h) { return h ? h->err.c_str() : g_create
 // v moved through it; profiles/experiments_r2.md 15).  A fresh device hands out neighbouring memory, so x and v of a
 // default allocation share a region almost always.
 // For particle states that live in HBM (>= 256 MB) x and v are therefore two allocations: x first, then blocks of the same
-// size one after the other (they are laid down in sequence, 32 GiB is at most 64 blocks of config 2); every few blocks the
-// pair (x, block) is timed with a streaming pass, the first pair of the fast kind wins, everything else is freed
-// before pic_create returns.  Never more than a third of the free memory is held (the partner region can be 64 GiB away).
-// Smaller states keep x | v in one block (they sit in the Infinity Cache, and the one-copy read-back of
-// pic_get_particles wants them adjacent).  If no pair reaches kFastGBs the best one seen is kept.
+// size one after the other (they are laid down in sequence); every few blocks the pair (x, block) is timed with a streaming
+// pass.  The search is a policy on RATIOS, not on this part's numbers: it ends when the best pair seen streams >= 10 % faster
+// than the slowest one seen (the two kinds have been told apart and we hold a fast one), after six timed pairs without an
+// improvement (all pairs alike on this device: nothing to gain), after 100 ms, or when a third of the free memory is
+// held; everything but x and v is freed before pic_create returns.  pic_config.placement = PIC_PLACE_OFF skips it (x | v in
+// one block).  Smaller states keep x | v in one block too (they sit in the Infinity Cache, and the one-copy read-back of
+// pic_get_particles wants them adjacent).
 hipError_t alloc_particles(pic_handle* h, size_t pbytes) {
   constexpr size_t kMinBytes = (size_t)256 << 20;
   constexpr size_t kStride = (size_t)3 << 30;       // memory laid down between two timed candidates (a region is 32 GiB)
-  constexpr double kFastGBs = 5880.0;               // streaming rate of a pair of the fast kind (slow 5000-5300, in between 5400-5800, fast 5900-6050)
+  constexpr double kGain = 1.10;                    // best / slowest rate at which the search has found what it looks for
+  constexpr int kPatience = 6;                      // timed pairs without improvement before giving up
+  constexpr double kMaxSeconds = 0.100;
   constexpr int kMaxBlocks = 192;
-  if (2 * pbytes < kMinBytes) {
+  if (2 * pbytes < kMinBytes || h->cfg.placement == PIC_PLACE_OFF) {
     const hipError_t e = hipMalloc(&h->x, 2 * pbytes);
     h->v = static_cast<char*>(h->x) + pbytes;
     return e;
   }
+  const auto t_begin = std::chrono::steady_clock::now();
+  auto seconds = [&]() { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count(); };
   hipError_t e = hipMalloc(&h->x, pbytes);
   if (e != hipSuccess) return e;
   h->v_separate = true;
@@ -525,17 +562,17 @@ hipError_t alloc_particles(pic_handle* h, size_t pbytes) {
     double2* b = static_cast<double2*>(vb);
     bool good = hipMemsetAsync(vb, 0, pbytes, h->stream) == hipSuccess;
     hipLaunchKernelGGL(stream_probe_kernel, dim3((unsigned)nb), dim3(BLOCK), 0, h->stream, a, b, n2, chunk2, 1.0, 0);
-    good = good && hipEventRecord(e0, h->stream) == hipSuccess;
+    good = good && hipGetLastError() == hipSuccess && hipEventRecord(e0, h->stream) == hipSuccess;
     for (int r = 0; r < 2; ++r)
       hipLaunchKernelGGL(stream_probe_kernel, dim3((unsigned)nb), dim3(BLOCK), 0, h->stream, a, b, n2, chunk2, 1.0, 0);
-    return good && hipEventRecord(e1, h->stream) == hipSuccess && hipEventSynchronize(e1) == hipSuccess &&
-           hipEventElapsedTime(ms, e0, e1) == hipSuccess;
+    return good && hipGetLastError() == hipSuccess && hipEventRecord(e1, h->stream) == hipSuccess &&
+           hipEventSynchronize(e1) == hipSuccess && hipEventElapsedTime(ms, e0, e1) == hipSuccess;
   };
   const double gb_per_ms = 2.0 * 4.0 * (double)pbytes / 1e6;          // 2 passes, 2 arrays read and written: GB/s = this / ms
   std::vector<void*> blocks;                                          // every block taken after x, in order
   void* best = nullptr;
   float best_ms = 0.f, worst_ms = 0.f;
-  int timed = 0;
+  int timed = 0, since_better = 0;
   size_t since_timed = kStride;                                       // the first block is timed
   if (ok) ok = hipMemsetAsync(h->x, 0, pbytes, h->stream) == hipSuccess;
   while (ok && (int)blocks.size() < kMaxBlocks && (blocks.size() + 2) * pbytes <= budget) {
@@ -549,9 +586,10 @@ hipError_t alloc_particles(pic_handle* h, size_t pbytes) {
     ok = pair_ms(b, &ms);
     if (!ok) break;
     ++timed;
-    if (!best || ms < best_ms) { best = b; best_ms = ms; }
+    if (!best || ms < best_ms) { best = b; best_ms = ms; since_better = 0; } else ++since_better;
     if (ms > worst_ms) worst_ms = ms;
-    if (gb_per_ms / best_ms >= kFastGBs) break;
+    if (worst_ms >= kGain * best_ms) break;                           // a fast pair, known to be one
+    if (since_better >= kPatience || seconds() > kMaxSeconds) break;
   }
   if (e0) hipEventDestroy(e0);
   if (e1) hipEventDestroy(e1);
@@ -572,6 +610,7 @@ hipError_t alloc_particles(pic_handle* h, size_t pbytes) {
     h->place_gbs[0] = gb_per_ms / best_ms;
     h->place_gbs[1] = gb_per_ms / worst_ms;
   }
+  h->place_seconds = seconds();
   return hipSuccess;
 }
 
@@ -597,6 +636,8 @@ int pic_create(const pic_config* cfg, pic_handle** out) {
     return fail(nullptr, PIC_EINVAL, "pic_create: the packed accumulator needs float32 particles");
   if (cfg->accum_dtype == PIC_ACC_PACKED && cfg->interpol != PIC_CIC)
     return fail(nullptr, PIC_EINVAL, "pic_create: the packed accumulator is CIC only");
+  if (cfg->placement != PIC_PLACE_AUTO && cfg->placement != PIC_PLACE_OFF)
+    return fail(nullptr, PIC_EINVAL, "pic_create: placement must be PIC_PLACE_AUTO or PIC_PLACE_OFF");
   if (cfg->accum_dtype == PIC_ACC_F64 && cfg->particle_dtype != PIC_F64)
     return fail(nullptr, PIC_EINVAL, "pic_create: the float64 accumulator needs float64 particles");
 
@@ -644,6 +685,10 @@ int pic_create(const pic_config* cfg, pic_handle** out) {
     if (nblk > max_by_work) nblk = max_by_work;
     if (nblk < 1) nblk = 1;
   }
+  {                                          // a workgroup's chunk of x or v is addressed with 31-bit byte offsets (StreamOut)
+    const long long cap = (1ll << 27) - tile;
+    if (nblk < (cfg->N + cap - 1) / cap) nblk = (cfg->N + cap - 1) / cap;
+  }
   if (h->acc_kind == PIC_ACC_PACKED) {       // count field of the packed accumulator: < 2^20 particles per workgroup
     const long long cap = (1ll << 20) - tile;
     if (nblk < (cfg->N + cap - 1) / cap) nblk = (cfg->N + cap - 1) / cap;
@@ -654,6 +699,13 @@ int pic_create(const pic_config* cfg, pic_handle** out) {
   if (nblk > 65535) { delete h; return fail(nullptr, PIC_EINVAL, "pic_create: blocks_per_env too large"); }
   h->chunk = chunk;
   h->nblk = (int)nblk;
+  // Sub-rows of an accumulator row (pic_device.h: acc_row_sum): with few environments all workgroups of an environment flush
+  // at about the same time, and their atomics on one 8 Ng-byte row are serialised at the memory side.  At most 4 sub-rows (1 / 2 /
+  // 3 / 4 environments of 1e6: 31.2 / 45.0 / 64.5 / 74.0 us per step with 4, 31.6 / 45.3 / 65.5 / 75.1 with 8, 33.3 / 47.8 /
+  // 65.2 / 75.4 with 16: every reader sums them), at least 8 workgroups per sub-row; with 16 environments or more the rows
+  // themselves spread the traffic (and the flushes hide under the streaming of the other workgroups).
+  h->S = 1;
+  while (h->S < 4 && nblk / (2 * h->S) >= 8 && (long long)cfg->num_envs * 2 * h->S <= 32) h->S *= 2;
 
   const size_t stride = (size_t)cfg->Ng + 2;
   // LDS: 2 R meshes (sweep D deposits two) + the field tile.  R = 1: one mesh for the eight waves of a workgroup.  Copies per
@@ -663,9 +715,13 @@ int pic_create(const pic_config* cfg, pic_handle** out) {
   h->R = 1;
   h->sweep_lds = 2 * h->R * stride * 8 + stride * h->esz;
   h->solve_lds = 2 * (size_t)cfg->Ng * sizeof(double);
-  if (h->sweep_lds > 64 * 1024) {
+  // a workgroup may use 64 KB of LDS: the dynamic part sized here plus the kernels' static arrays (kSweepStaticLds, kResidentStaticLds)
+  constexpr size_t kLdsLimit = 64 * 1024;
+  if (h->sweep_lds + kSweepStaticLds > kLdsLimit) {
+    const long long max_ng = (long long)((kLdsLimit - kSweepStaticLds) / (2 * h->R * 8 + h->esz)) - 2;
     delete h;
-    return fail(nullptr, PIC_EINVAL, "pic_create: Ng too large for the LDS-resident mesh (max 2700 cells)");
+    return fail(nullptr, PIC_EINVAL, "pic_create: Ng too large for the LDS-resident mesh (at most " + std::to_string(max_ng) +
+                                     " cells with this particle dtype)");
   }
   // Resident schedule (pic_resident.h): environments whose particles fit one workgroup's registers are stepped by
   // one launch per pic_step call.  blocks_per_env: 0 = use it where it applies, > 0 = streaming sweeps with that many
@@ -680,10 +736,12 @@ int pic_create(const pic_config* cfg, pic_handle** out) {
     auto need = [&](int R) { return (size_t)2 * R * stride * 8 + 4 * (size_t)cfg->Ng * 8 + stride * h->esz; };
     while (h->res_R > 1 && need(h->res_R) > 48 * 1024) h->res_R >>= 1;
     h->res_lds = need(h->res_R);
-    const bool possible = h->res_nw != 0 && h->res_lds <= 64 * 1024 && h->acc_kind != PIC_ACC_F64;
+    const bool possible = h->res_nw != 0 && h->res_lds + kResidentStaticLds <= kLdsLimit && h->acc_kind != PIC_ACC_F64;
     if (cfg->blocks_per_env < 0 && !possible) {
+      const long long max_ng = (long long)((kLdsLimit - kResidentStaticLds - 2 * (2 * 8 + h->esz)) / (2 * 8 + h->esz + 4 * 8));
       delete h;
-      return fail(nullptr, PIC_EINVAL, "pic_create: the resident schedule needs N <= 8192, Ng <= 1160 and an integer accumulator");
+      return fail(nullptr, PIC_EINVAL, "pic_create: the resident schedule needs N <= 8192, Ng <= " + std::to_string(max_ng) +
+                                       " (this particle dtype) and an integer accumulator");
     }
     // Measured (profiles/experiments_r2.md): one workgroup steps 5000 float64 particles in ~17 us whatever the number of
     // environments, the sweeps need 22 us for one environment of 8000 and 35-110 us for 64-1024 of 5000.  A lone
@@ -718,10 +776,15 @@ int pic_create(const pic_config* cfg, pic_handle** out) {
   // together into pinned memory instead of two copies into pageable memory
   if (2 * (size_t)cfg->num_envs * cfg->N * h->esz <= ((size_t)4 << 20))
     CREATE_CHK(hipHostMalloc(&h->h_part, 2 * (size_t)cfg->num_envs * cfg->N * h->esz, hipHostMallocDefault));
-  CREATE_CHK(hipMalloc((void**)&h->ring, (size_t)(RING + 1) * gbytes));      // acc_t and double are both 8 bytes
-  CREATE_CHK(hipMemsetAsync(h->ring, 0, (size_t)(RING + 1) * gbytes, h->stream));
-  h->probe_acc = h->ring + (size_t)RING * cfg->num_envs * cfg->Ng;
+  CREATE_CHK(hipMalloc((void**)&h->ring, (size_t)(RING + 1) * h->S * gbytes));      // acc_t and double are both 8 bytes
+  CREATE_CHK(hipMemsetAsync(h->ring, 0, (size_t)(RING + 1) * h->S * gbytes, h->stream));
+  h->probe_acc = ring_row(h, RING);
   for (int s = 0; s < RING; ++s) h->clean.push_back(s);
+  if (h->resident) {
+    const size_t qbytes = (size_t)cfg->num_envs * h->res_R * stride * sizeof(unsigned long long);
+    CREATE_CHK(hipMalloc((void**)&h->res_q1, qbytes));
+    CREATE_CHK(hipMemsetAsync(h->res_q1, 0, qbytes, h->stream));
+  }
   CREATE_CHK(hipMalloc((void**)&h->ke_part, (size_t)cfg->num_envs * h->nblk * sizeof(double)));
   CREATE_CHK(hipMemsetAsync(h->ke_part, 0, (size_t)cfg->num_envs * h->nblk * sizeof(double), h->stream));
   double** grids[] = {&h->n, &h->E_mesh, &h->phi, &h->ext, &h->probe_ext, &h->aux_n, &h->aux_E, &h->aux_phi};
@@ -754,7 +817,7 @@ int pic_destroy(pic_handle* h) {
   prof_drain(h);
   for (hipEvent_t e : h->ev) hipEventDestroy(e);
   void* bufs[] = {h->x, h->scratch, h->stage, h->ring, h->ke_part, h->n, h->E_mesh, h->phi, h->ext, h->probe_ext,
-                  h->basis, h->act, h->modes, h->aux_n, h->aux_E, h->aux_pe, h->aux_phi, h->KE, h->bad};
+                  h->basis, h->act, h->modes, h->aux_n, h->aux_E, h->aux_pe, h->aux_phi, h->KE, h->bad, h->tw, h->traj, h->res_q1};
   for (void* b : bufs)
     if (b) hipFree(b);
   if (h->v_separate && h->v) hipFree(h->v);
@@ -785,11 +848,13 @@ int pic_own_stream(pic_handle* h) {
 
 int pic_schedule(pic_handle* h) { return h ? (h->resident ? 1 : 0) : PIC_EINVAL; }
 
-int pic_placement_info(pic_handle* h, int* candidates, double* kept_gbytes_per_s, double* slowest_gbytes_per_s) {
+int pic_placement_info(pic_handle* h, int* candidates, double* kept_gbytes_per_s, double* slowest_gbytes_per_s,
+                       double* seconds) {
   if (!h) return PIC_EINVAL;
   if (candidates) *candidates = h->place_tried;
   if (kept_gbytes_per_s) *kept_gbytes_per_s = h->place_gbs[0];
   if (slowest_gbytes_per_s) *slowest_gbytes_per_s = h->place_gbs[1];
+  if (seconds) *seconds = h->place_seconds;
   return PIC_OK;
 }
 
@@ -836,21 +901,21 @@ int pic_reset(pic_handle* h, const void* x0, const void* v0, int mem_kind) {
 }
 
 // the sweeps of one environment step; `upto`: 1 = through sweep B, 2 = through C, 3 = whole step.  from: first
-// stage to run (1, 2, 3).  Each force evaluation takes `ext` (may differ per stage in the staged entry point).
-// another_step_follows (the steps of one pic_step call but the last): the post-step solve of this step is not launched; the
+// stage to run (1, 2, 3).  Each force evaluation takes `ctl` (may differ per stage in the staged entry point).
+// another_step_follows (the steps of one call but the last): the post-step solve of this step is not launched; the
 // next step's sweep B carries it in one extra workgroup per environment (its results -- n, E_mesh, phi, the energies --
 // are read by nothing inside the call, and the last step's solve is a launch of its own as ever).
-static void run_stages(pic_handle* h, int from, int upto, const double* ext, bool another_step_follows = false) {
+static void run_stages(pic_handle* h, int from, int upto, const Control& ctl, bool another_step_follows = false) {
   const double* c = h->cs;
   const double* d = h->ds;
   for (int st = from; st <= upto; ++st) {
     if (st == 1) {
       if (h->q_slot < 0) {          // particles were loaded without a refresh: deposit q1 = x + (c1 v) dt now
         h->q_slot = ring_take_clean(h);
-        launch_sweep(h, ST_A, h->x, h->v, 0.0, c[0], 0.0, -1, nullptr, ring_row(h, h->q_slot), nullptr);
+        launch_sweep(h, ST_A, h->x, h->v, 0.0, c[0], 0.0, -1, Control{}, ring_row(h, h->q_slot), nullptr);
       }
       const int x1 = ring_take_clean(h);
-      launch_sweep(h, ST_B, h->x, h->v, c[0], c[1], d[1], h->q_slot, ext, ring_row(h, x1), nullptr, h->post_slot);
+      launch_sweep(h, ST_B, h->x, h->v, c[0], c[1], d[1], h->q_slot, ctl, ring_row(h, x1), nullptr, h->post_slot);
       ring_retire(h, h->post_slot);
       h->post_slot = -1;
       ring_retire(h, h->q_slot);
@@ -858,12 +923,12 @@ static void run_stages(pic_handle* h, int from, int upto, const double* ext, boo
       h->stage_slot = x1;
     } else if (st == 2) {
       const int x2 = ring_take_clean(h);
-      launch_sweep(h, ST_C, h->x, h->v, 0.0, c[2], d[2], h->stage_slot, ext, ring_row(h, x2), nullptr);
+      launch_sweep(h, ST_C, h->x, h->v, 0.0, c[2], d[2], h->stage_slot, ctl, ring_row(h, x2), nullptr);
       ring_retire(h, h->stage_slot);
       h->stage_slot = x2;
     } else {
       const int f = ring_take_clean(h), qn = ring_take_clean(h);
-      launch_sweep(h, ST_D, h->x, h->v, 0.0, c[3], d[3], h->stage_slot, ext, ring_row(h, f), ring_row(h, qn));
+      launch_sweep(h, ST_D, h->x, h->v, 0.0, c[3], d[3], h->stage_slot, ctl, ring_row(h, f), ring_row(h, qn));
       ring_retire(h, h->stage_slot);
       h->stage_slot = -1;
       if (another_step_follows) { h->post_slot = f; h->post_hist_row = h->hist_row; }
@@ -871,6 +936,17 @@ static void run_stages(pic_handle* h, int from, int upto, const double* ext, boo
       h->q_slot = qn;
     }
   }
+}
+
+// host -> device staging of a call's inputs.  Small per-step inputs have buffers of their own (h->ext, h->act); whole
+// trajectories go through h->traj, grown on demand (growing drains the stream first).
+static int ensure_traj(pic_handle* h, size_t bytes) {
+  if (bytes <= h->traj_bytes) return PIC_OK;
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  if (h->traj) { hipFree(h->traj); h->traj = nullptr; h->traj_bytes = 0; }
+  if (hipMalloc(&h->traj, bytes) != hipSuccess) return fail(h, PIC_ENOMEM, "trajectory staging buffer");
+  h->traj_bytes = bytes;
+  return PIC_OK;
 }
 
 static int stage_ext(pic_handle* h, const double* E_ext, int mem_kind, const double** ext) {
@@ -885,110 +961,151 @@ static int stage_ext(pic_handle* h, const double* E_ext, int mem_kind, const dou
   return PIC_OK;
 }
 
+static int ensure_twiddle(pic_handle* h, int rows) {
+  if (rows <= h->tw_rows) return PIC_OK;
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  if (h->tw) { hipFree(h->tw); h->tw = nullptr; h->tw_rows = 0; }
+  HIPCHK(h, hipMalloc((void**)&h->tw, (size_t)2 * rows * h->cfg.Ng * sizeof(double)));
+  hipLaunchKernelGGL(twiddle_kernel, dim3((h->cfg.Ng + BLOCK - 1) / BLOCK, rows), dim3(BLOCK), 0, h->stream, h->tw, h->cfg.Ng, rows);
+  HIPCHK(h, hipGetLastError());
+  h->tw_rows = rows;
+  return PIC_OK;
+}
+
+// nsteps x PIC.update_state under `sc`, all launches enqueued, no host synchronisation.  hist: device [nsteps][3][env] record of
+// the energies, or null; snap (resident schedule only): device record of the particles.
+static int advance(pic_handle* h, const StepControl& sc, int nsteps, double* hist, void* snap = nullptr) {
+  if (nsteps <= 0) return PIC_OK;
+  const int E = h->cfg.num_envs;
+  if (h->resident) {
+    launch_resident(h, sc, nsteps, hist, snap);
+    ring_retire(h, h->q_slot);       // the ring's q1 deposit belongs to the particles before these steps
+    ring_retire(h, h->stage_slot);
+    h->q_slot = h->stage_slot = -1;
+    HIPCHK(h, hipGetLastError());
+    return PIC_OK;
+  }
+  const size_t act_row = (size_t)E * 2 * sc.ctl.M;
+  for (int s = 0; s < nsteps; ++s) {
+    Control ctl = sc.ctl;
+    if (ctl.ext) ctl.ext += (size_t)s * sc.ext_step;
+    if (ctl.act) ctl.act += (size_t)s * sc.act_step;
+    h->hist_row = hist ? hist + (size_t)s * 3 * E : nullptr;
+    bool rides = s + 1 < nsteps;     // the post-step solve rides with the next step's sweep B
+    if (sc.fb.M > 0) {
+      // The action of step s is the feedback law's on the field step s-1 left: the post-step solve is on the critical path
+      // (a launch of its own that also computes the next action); before the first step a small kernel does it.
+      Feedback fb = sc.fb;
+      fb.act_out = h->act;
+      if (s == 0) {
+        hipLaunchKernelGGL(feedback_kernel, dim3(E), dim3(BLOCK), 0, h->stream, h->E_mesh, fb, h->cfg.Ng);
+      }
+      ctl.act = h->act;
+      ctl.ext = nullptr;
+      rides = false;
+      h->fb = Feedback{};
+      if (s + 1 < nsteps) {
+        h->fb = fb;
+        if (fb.act_hist) h->fb.act_hist = fb.act_hist + (size_t)(s + 1) * act_row;
+      }
+    }
+    run_stages(h, 1, 3, ctl, rides);
+  }
+  h->hist_row = h->post_hist_row = nullptr;
+  h->fb = Feedback{};
+  HIPCHK(h, hipGetLastError());
+  return PIC_OK;
+}
+
 int pic_step_stage(pic_handle* h, int stage, const double* E_ext, int mem_kind) {
   if (!h) return PIC_EINVAL;
   if (!h->has_state) return fail(h, PIC_ESTATE, "pic_step_stage: call pic_reset first");
   if (stage < 1 || stage > 3 || stage != h->mid_stage + 1)
     return fail(h, PIC_ESTATE, "pic_step_stage: stages run in the order 1, 2, 3");
   HIPCHK(h, hipSetDevice(h->cfg.device_id));
-  const double* ext;
-  int rc = stage_ext(h, E_ext, mem_kind, &ext);
+  Control ctl{};
+  int rc = stage_ext(h, E_ext, mem_kind, &ctl.ext);
   if (rc) return rc;
-  run_stages(h, stage, stage, ext);
+  h->res_q1_valid = false;           // (a resident handle steps by sweeps here: its carried q1 mesh goes stale)
+  run_stages(h, stage, stage, ctl);
   h->mid_stage = stage == 3 ? 0 : stage;
   HIPCHK(h, hipGetLastError());
   return PIC_OK;
 }
 
-int pic_step(pic_handle* h, const double* E_ext, int mem_kind, int nsteps) {
-  if (!h) return PIC_EINVAL;
-  if (!h->has_state) return fail(h, PIC_ESTATE, "pic_step: call pic_reset first");
-  if (nsteps < 0) return fail(h, PIC_EINVAL, "pic_step: nsteps < 0");
-  if (h->mid_stage) return fail(h, PIC_ESTATE, "pic_step: a staged step is in progress (finish pic_step_stage 1..3)");
-  HIPCHK(h, hipSetDevice(h->cfg.device_id));
-  const double* ext;
-  int rc = stage_ext(h, E_ext, mem_kind, &ext);
-  if (rc) return rc;
-  if (h->resident) {
-    if (nsteps > 0) {
-      launch_resident(h, ext, nsteps, nullptr);
-      drop_cached_deposits(h);       // the ring's q1 deposit belongs to the particles before these steps
-    }
-  } else {
-    for (int s = 0; s < nsteps; ++s) run_stages(h, 1, 3, ext, /*another_step_follows=*/s + 1 < nsteps);
-  }
-  HIPCHK(h, hipGetLastError());
+static int check_steppable(pic_handle* h, int nsteps, const char* who) {
+  if (!h->has_state) return fail(h, PIC_ESTATE, std::string(who) + ": call pic_reset first");
+  if (nsteps < 0) return fail(h, PIC_EINVAL, std::string(who) + ": nsteps < 0");
+  if (h->mid_stage) return fail(h, PIC_ESTATE, std::string(who) + ": a staged step is in progress (finish pic_step_stage 1..3)");
   return PIC_OK;
 }
 
-// nsteps steps with the energies (hist, may be null) and / or the particles (snap, may be null) of every step kept on
-// the device and read back once at the end
-static int step_recording(pic_handle* h, const double* E_ext, int mem_kind, int nsteps, double* hist, void* snap,
-                          const char* who) {
-  if (nsteps < 0) return fail(h, PIC_EINVAL, std::string(who) + ": nsteps < 0");
-  if (nsteps == 0) return PIC_OK;
-  if (!h->has_state) return fail(h, PIC_ESTATE, std::string(who) + ": call pic_reset first");
-  if (h->mid_stage) return fail(h, PIC_ESTATE, std::string(who) + ": a staged step is in progress (finish pic_step_stage 1..3)");
+int pic_step(pic_handle* h, const double* E_ext, int mem_kind, int nsteps) {
+  if (!h) return PIC_EINVAL;
+  int rc = check_steppable(h, nsteps, "pic_step");
+  if (rc) return rc;
   HIPCHK(h, hipSetDevice(h->cfg.device_id));
+  StepControl sc;
+  rc = stage_ext(h, E_ext, mem_kind, &sc.ctl.ext);
+  if (rc) return rc;
+  return advance(h, sc, nsteps, nullptr);
+}
+
+// Runs `sc` for nsteps steps with the energies (hist, may be null) and / or the particles (snap, may be null) of every step
+// kept on the device and read back once at the end; act_out (may be null): host [nsteps][env][2M] record of the feedback
+// law's actions.  Returns after the read-backs, or -- nothing to read back -- without waiting for the device.
+static int step_recording(pic_handle* h, StepControl sc, int nsteps, double* hist, void* snap, double* act_out, const char* who) {
+  if (nsteps == 0) return PIC_OK;
   const int E = h->cfg.num_envs;
   const size_t hbytes = (size_t)nsteps * 3 * E * sizeof(double);
   const size_t sbytes = (size_t)nsteps * 2 * E * (size_t)h->cfg.N * h->esz;
+  const size_t abytes = (size_t)nsteps * E * 2 * sc.fb.M * sizeof(double);
   double* dh = nullptr;
+  double* da = nullptr;
   void* ds = nullptr;
+  auto release = [&]() { if (dh) hipFree(dh); if (da) hipFree(da); if (ds) hipFree(ds); };
   if (hist && hipMalloc((void**)&dh, hbytes) != hipSuccess) return fail(h, PIC_ENOMEM, std::string(who) + ": history buffer");
+  if (act_out && sc.fb.M > 0 && hipMalloc((void**)&da, abytes) != hipSuccess) { release(); return fail(h, PIC_ENOMEM, std::string(who) + ": action record"); }
   if (snap && hipMalloc(&ds, sbytes) != hipSuccess) {
-    if (dh) hipFree(dh);
+    release();
     return fail(h, PIC_ENOMEM, std::string(who) + ": the snapshots of all steps do not fit on the device; record fewer steps per call");
   }
-  // the external field is uploaded once; the per-step calls then take it from the device
-  const double* ext = E_ext;
-  int kind = mem_kind;
+  sc.fb.act_hist = da;
   int rc = PIC_OK;
-  hipError_t e = hipSuccess;
-  if (E_ext && mem_kind == PIC_HOST) {
-    e = hipMemcpyAsync(h->ext, E_ext, (size_t)E * h->cfg.Ng * sizeof(double), hipMemcpyHostToDevice, h->stream);
-    ext = h->ext;
-    kind = PIC_DEVICE;
-  }
-  if (e == hipSuccess) {
-    if (h->resident) {
-      launch_resident(h, ext, nsteps, dh, ds);        // the kernel records every step itself
-      drop_cached_deposits(h);
-    } else {
-      const dim3 grid = aux_grid(h, E);
-      if (!ds) {       // energies only: every post-step solve records its own entry (the ones riding with sweep B included)
-        for (int s = 0; s < nsteps; ++s) {
-          h->hist_row = dh ? dh + (size_t)s * 3 * E : nullptr;
-          run_stages(h, 1, 3, ext, /*another_step_follows=*/s + 1 < nsteps);
-        }
-        h->hist_row = h->post_hist_row = nullptr;
-      } else
-      for (int s = 0; s < nsteps && rc == PIC_OK; ++s) {
-        rc = pic_step(h, ext, kind, 1);
-        if (rc != PIC_OK) break;
-        if (dh)
-          hipLaunchKernelGGL(record_energies_kernel, dim3((E + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, h->stream, h->KE, h->PE,
-                             h->PEr, dh, s, E);
-        if (ds) {
-          if (h->fmt == FMT_F64)
-            hipLaunchKernelGGL(record_particles_kernel<PosF64>, grid, dim3(BLOCK), 0, h->stream, (const double*)h->x,
-                               (const double*)h->v, (double*)ds, s, h->cfg.N, h->ld, h->cfg.L);
-          else if (h->fmt == FMT_F32)
-            hipLaunchKernelGGL(record_particles_kernel<PosF32>, grid, dim3(BLOCK), 0, h->stream, (const float*)h->x,
-                               (const float*)h->v, (float*)ds, s, h->cfg.N, h->ld, h->cfg.L);
-          else
-            hipLaunchKernelGGL(record_particles_kernel<PosU32>, grid, dim3(BLOCK), 0, h->stream, (const unsigned*)h->x,
-                               (const float*)h->v, (float*)ds, s, h->cfg.N, h->ld, h->cfg.L);
-        }
-      }
+  if (!ds || h->resident) {
+    rc = advance(h, sc, nsteps, dh, ds);      // energies: every post-step solve records its own entry; resident: the kernel records all
+  } else {
+    // particle snapshots on the streaming schedule: step by step, a copy kernel after each
+    const dim3 grid = aux_grid(h, E);
+    for (int s = 0; s < nsteps && rc == PIC_OK; ++s) {
+      StepControl one = sc;
+      if (one.ctl.ext) one.ctl.ext += (size_t)s * sc.ext_step;
+      if (one.ctl.act) one.ctl.act += (size_t)s * sc.act_step;
+      if (one.fb.act_hist) one.fb.act_hist += (size_t)s * E * 2 * sc.fb.M;
+      rc = advance(h, one, 1, dh ? dh + (size_t)s * 3 * E : nullptr);
+      if (rc != PIC_OK) break;
+      if (h->fmt == FMT_F64)
+        hipLaunchKernelGGL(record_particles_kernel<PosF64>, grid, dim3(BLOCK), 0, h->stream, (const double*)h->x,
+                           (const double*)h->v, (double*)ds, s, h->cfg.N, h->ld, h->cfg.L);
+      else if (h->fmt == FMT_F32)
+        hipLaunchKernelGGL(record_particles_kernel<PosF32>, grid, dim3(BLOCK), 0, h->stream, (const float*)h->x,
+                           (const float*)h->v, (float*)ds, s, h->cfg.N, h->ld, h->cfg.L);
+      else
+        hipLaunchKernelGGL(record_particles_kernel<PosU32>, grid, dim3(BLOCK), 0, h->stream, (const unsigned*)h->x,
+                           (const float*)h->v, (float*)ds, s, h->cfg.N, h->ld, h->cfg.L);
     }
-    e = hipGetLastError();
+  }
+  hipError_t e = hipGetLastError();
+  if (!dh && !da && !ds) {
+    if (rc != PIC_OK) return rc;
+    if (e != hipSuccess) return fail(h, PIC_EHIP, std::string(who) + ": " + hipGetErrorString(e));
+    return PIC_OK;
   }
   if (rc == PIC_OK && e == hipSuccess && dh) e = hipMemcpyAsync(hist, dh, hbytes, hipMemcpyDeviceToHost, h->stream);
+  if (rc == PIC_OK && e == hipSuccess && da) e = hipMemcpyAsync(act_out, da, abytes, hipMemcpyDeviceToHost, h->stream);
   if (rc == PIC_OK && e == hipSuccess && ds) e = hipMemcpyAsync(snap, ds, sbytes, hipMemcpyDeviceToHost, h->stream);
   hipError_t e2 = hipStreamSynchronize(h->stream);
-  if (dh) hipFree(dh);
-  if (ds) hipFree(ds);
+  release();
   if (rc != PIC_OK) return rc;
   if (e != hipSuccess || e2 != hipSuccess)
     return fail(h, PIC_EHIP, std::string(who) + ": " + hipGetErrorString(e != hipSuccess ? e : e2));
@@ -997,12 +1114,48 @@ static int step_recording(pic_handle* h, const double* E_ext, int mem_kind, int 
 
 int pic_step_history(pic_handle* h, const double* E_ext, int mem_kind, int nsteps, double* hist) {
   if (!h || !hist) return fail(h, PIC_EINVAL, "pic_step_history: null argument");
-  return step_recording(h, E_ext, mem_kind, nsteps, hist, nullptr, "pic_step_history");
+  int rc = check_steppable(h, nsteps, "pic_step_history");
+  if (rc) return rc;
+  HIPCHK(h, hipSetDevice(h->cfg.device_id));
+  StepControl sc;
+  rc = stage_ext(h, E_ext, mem_kind, &sc.ctl.ext);
+  if (rc) return rc;
+  return step_recording(h, sc, nsteps, hist, nullptr, nullptr, "pic_step_history");
 }
 
 int pic_step_snapshots(pic_handle* h, const double* E_ext, int mem_kind, int nsteps, void* snap, double* hist) {
   if (!h || !snap) return fail(h, PIC_EINVAL, "pic_step_snapshots: null argument");
-  return step_recording(h, E_ext, mem_kind, nsteps, hist, snap, "pic_step_snapshots");
+  int rc = check_steppable(h, nsteps, "pic_step_snapshots");
+  if (rc) return rc;
+  HIPCHK(h, hipSetDevice(h->cfg.device_id));
+  StepControl sc;
+  rc = stage_ext(h, E_ext, mem_kind, &sc.ctl.ext);
+  if (rc) return rc;
+  return step_recording(h, sc, nsteps, hist, snap, nullptr, "pic_step_snapshots");
+}
+
+// a per-step input trajectory [nsteps][row] (host or device) -> device pointer
+static int stage_traj(pic_handle* h, const double* src, int mem_kind, size_t row_elems_, int nsteps, const double** dev) {
+  *dev = src;
+  if (mem_kind != PIC_HOST) return PIC_OK;
+  const size_t bytes = (size_t)nsteps * row_elems_ * sizeof(double);
+  int rc = ensure_traj(h, bytes);
+  if (rc) return rc;
+  HIPCHK(h, hipMemcpyAsync(h->traj, src, bytes, hipMemcpyHostToDevice, h->stream));
+  *dev = static_cast<const double*>(h->traj);
+  return PIC_OK;
+}
+
+int pic_step_ext_traj(pic_handle* h, const double* E_ext_traj, int mem_kind, int nsteps, double* hist, void* snap) {
+  if (!h || !E_ext_traj) return fail(h, PIC_EINVAL, "pic_step_ext_traj: null argument");
+  int rc = check_steppable(h, nsteps, "pic_step_ext_traj");
+  if (rc) return rc;
+  HIPCHK(h, hipSetDevice(h->cfg.device_id));
+  StepControl sc;
+  sc.ext_step = (long long)h->cfg.num_envs * h->cfg.Ng;
+  rc = stage_traj(h, E_ext_traj, mem_kind, (size_t)sc.ext_step, nsteps, &sc.ctl.ext);
+  if (rc) return rc;
+  return step_recording(h, sc, nsteps, hist, snap, nullptr, "pic_step_ext_traj");
 }
 
 int pic_get_particles(pic_handle* h, void* x, void* v, int mem_kind) {
@@ -1122,8 +1275,8 @@ static int probe_solve(pic_handle* h, const double* E_ext, bool want_phi) {
     HIPCHK(h, hipMemcpyAsync(h->probe_ext, E_ext, gbytes, hipMemcpyHostToDevice, h->stream));
     ext = h->probe_ext;
   }
-  HIPCHK(h, hipMemsetAsync(h->probe_acc, 0, gbytes, h->stream));
-  launch_sweep(h, ST_PROBE, h->scratch, h->scratch, 0, 0, 0, -1, nullptr, h->probe_acc, nullptr);
+  HIPCHK(h, hipMemsetAsync(h->probe_acc, 0, row_elems(h) * sizeof(acc_t), h->stream));
+  launch_sweep(h, ST_PROBE, h->scratch, h->scratch, 0, 0, 0, -1, Control{}, h->probe_acc, nullptr);
   SolveIO o{};
   o.acc = h->probe_acc; o.out.ext = ext; o.n = h->aux_n; o.out.E = h->aux_E; o.out.PEr = h->aux_pe;
   if (want_phi) o.out.phi = h->aux_phi;
@@ -1233,21 +1386,59 @@ int pic_set_actuator(pic_handle* h, int max_mode, const double* basis_cos, const
   return PIC_OK;
 }
 
+static int actuator_control(pic_handle* h, StepControl& sc, const char* who) {
+  if (!h->act_modes) return fail(h, PIC_ESTATE, std::string(who) + ": call pic_set_actuator first");
+  sc.ctl.basis = h->basis;
+  sc.ctl.M = h->act_modes;
+  return PIC_OK;
+}
+
 int pic_step_actions(pic_handle* h, const double* actions, int mem_kind, int nsteps) {
   if (!h || !actions) return fail(h, PIC_EINVAL, "pic_step_actions: null argument");
-  if (!h->act_modes) return fail(h, PIC_ESTATE, "pic_step_actions: call pic_set_actuator first");
+  int rc = check_steppable(h, nsteps, "pic_step_actions");
+  if (rc) return rc;
   HIPCHK(h, hipSetDevice(h->cfg.device_id));
-  const int M = h->act_modes, Ng = h->cfg.Ng;
-  const double* a = actions;
+  StepControl sc;
+  rc = actuator_control(h, sc, "pic_step_actions");
+  if (rc) return rc;
+  sc.ctl.act = actions;
   if (mem_kind == PIC_HOST) {
-    HIPCHK(h, hipMemcpyAsync(h->act, actions, (size_t)h->cfg.num_envs * 2 * M * sizeof(double), hipMemcpyHostToDevice,
+    HIPCHK(h, hipMemcpyAsync(h->act, actions, (size_t)h->cfg.num_envs * 2 * h->act_modes * sizeof(double), hipMemcpyHostToDevice,
                              h->stream));
-    a = h->act;
+    sc.ctl.act = h->act;
   }
-  hipLaunchKernelGGL(actuator_kernel, dim3((Ng + BLOCK - 1) / BLOCK, h->cfg.num_envs), dim3(BLOCK), 0, h->stream,
-                     h->basis, h->basis + (size_t)Ng * M, a, h->ext, Ng, M);
-  HIPCHK(h, hipGetLastError());
-  return pic_step(h, h->ext, PIC_DEVICE, nsteps);
+  return advance(h, sc, nsteps, nullptr);
+}
+
+int pic_step_actions_traj(pic_handle* h, const double* actions, int mem_kind, int nsteps, double* hist) {
+  if (!h || !actions) return fail(h, PIC_EINVAL, "pic_step_actions_traj: null argument");
+  int rc = check_steppable(h, nsteps, "pic_step_actions_traj");
+  if (rc) return rc;
+  HIPCHK(h, hipSetDevice(h->cfg.device_id));
+  StepControl sc;
+  rc = actuator_control(h, sc, "pic_step_actions_traj");
+  if (rc) return rc;
+  sc.act_step = (long long)h->cfg.num_envs * 2 * h->act_modes;
+  rc = stage_traj(h, actions, mem_kind, (size_t)sc.act_step, nsteps, &sc.ctl.act);
+  if (rc) return rc;
+  return step_recording(h, sc, nsteps, hist, nullptr, nullptr, "pic_step_actions_traj");
+}
+
+int pic_step_feedback(pic_handle* h, int max_mode, int nsteps, double* actions_out, double* hist) {
+  if (!h) return PIC_EINVAL;
+  int rc = check_steppable(h, nsteps, "pic_step_feedback");
+  if (rc) return rc;
+  HIPCHK(h, hipSetDevice(h->cfg.device_id));
+  StepControl sc;
+  rc = actuator_control(h, sc, "pic_step_feedback");
+  if (rc) return rc;
+  if (max_mode != h->act_modes || max_mode > kMaxFeedbackModes)
+    return fail(h, PIC_EINVAL, "pic_step_feedback: max_mode must equal the actuator's (pic_set_actuator) and be at most 16");
+  rc = ensure_twiddle(h, max_mode);
+  if (rc) return rc;
+  sc.fb.tw = h->tw; sc.fb.rows = h->tw_rows; sc.fb.M = max_mode;
+  sc.fb.act_out = h->act;
+  return step_recording(h, sc, nsteps, hist, nullptr, actions_out, "pic_step_feedback");
 }
 
 int pic_get_modes(pic_handle* h, int max_mode, double* re, double* im, int mem_kind) {
@@ -1261,10 +1452,12 @@ int pic_get_modes(pic_handle* h, int max_mode, double* re, double* im, int mem_k
     HIPCHK(h, hipMalloc((void**)&h->modes, 2 * nb));
     h->modes_cap = max_mode;
   }
+  int rc = ensure_twiddle(h, max_mode);
+  if (rc) return rc;
   double* dre = h->modes;
   double* dim_ = h->modes + (size_t)h->cfg.num_envs * max_mode;
-  hipLaunchKernelGGL(modes_kernel, dim3(max_mode, h->cfg.num_envs), dim3(BLOCK), 0, h->stream, h->E_mesh, dre, dim_,
-                     h->cfg.Ng, max_mode);
+  hipLaunchKernelGGL(modes_kernel, dim3(max_mode, h->cfg.num_envs), dim3(BLOCK), 0, h->stream, h->E_mesh, h->tw, h->tw_rows,
+                     dre, dim_, h->cfg.Ng, max_mode);
   HIPCHK(h, hipGetLastError());
   const hipMemcpyKind k = mem_kind == PIC_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
   if (re) HIPCHK(h, hipMemcpyAsync(re, dre, nb, k, h->stream));
@@ -1294,15 +1487,13 @@ int pic_reset_sampled(pic_handle* h, int kind, double a, double v0, double sigma
   return refresh_fields(h);      // a reset abandons an open staged step and any cached deposit
 }
 
-int pic_phase_histogram(pic_handle* h, int nbins, double vmin, double vmax, uint32_t* counts) {
-  if (!h || !counts || nbins < 1 || nbins > 4096 || !(vmax > vmin))
-    return fail(h, PIC_EINVAL, "pic_phase_histogram: need counts, 1 <= nbins <= 4096, vmax > vmin");
-  if (!h->has_state) return fail(h, PIC_ESTATE, "pic_phase_histogram: call pic_reset first");
-  HIPCHK(h, hipSetDevice(h->cfg.device_id));
+// counts[num_envs][nbins][nbins] of the current particles into a fresh device buffer (caller frees it)
+static hipError_t phase_counts(pic_handle* h, int nbins, double vmin, double vmax, unsigned** out) {
   const size_t nb = (size_t)h->cfg.num_envs * nbins * nbins * sizeof(unsigned);
   unsigned* d = nullptr;
-  HIPCHK(h, hipMalloc((void**)&d, nb));
-  hipError_t e = hipMemsetAsync(d, 0, nb, h->stream);
+  hipError_t e = hipMalloc((void**)&d, nb);
+  if (e != hipSuccess) return e;
+  e = hipMemsetAsync(d, 0, nb, h->stream);
   const dim3 grid = aux_grid(h, h->cfg.num_envs, 2048);
   if (e == hipSuccess) {
     if (h->fmt == FMT_F64)
@@ -1316,10 +1507,48 @@ int pic_phase_histogram(pic_handle* h, int nbins, double vmin, double vmax, uint
                          (const float*)h->v, d, h->cfg.N, h->ld, nbins, h->cfg.L, vmin, vmax);
     e = hipGetLastError();
   }
+  if (e != hipSuccess) { hipFree(d); return e; }
+  *out = d;
+  return hipSuccess;
+}
+
+int pic_phase_histogram(pic_handle* h, int nbins, double vmin, double vmax, uint32_t* counts) {
+  if (!h || !counts || nbins < 1 || nbins > 4096 || !(vmax > vmin))
+    return fail(h, PIC_EINVAL, "pic_phase_histogram: need counts, 1 <= nbins <= 4096, vmax > vmin");
+  if (!h->has_state) return fail(h, PIC_ESTATE, "pic_phase_histogram: call pic_reset first");
+  HIPCHK(h, hipSetDevice(h->cfg.device_id));
+  const size_t nb = (size_t)h->cfg.num_envs * nbins * nbins * sizeof(unsigned);
+  unsigned* d = nullptr;
+  hipError_t e = phase_counts(h, nbins, vmin, vmax, &d);
   if (e == hipSuccess) e = hipMemcpyAsync(counts, d, nb, hipMemcpyDeviceToHost, h->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
-  hipFree(d);
+  if (d) hipFree(d);
   if (e != hipSuccess) return fail(h, PIC_EHIP, std::string("pic_phase_histogram: ") + hipGetErrorString(e));
+  return PIC_OK;
+}
+
+int pic_phase_kl(pic_handle* h, int nbins, double vmin, double vmax, const double* feq, double* kl) {
+  if (!h || !feq || !kl || nbins < 1 || nbins > 4096 || !(vmax > vmin))
+    return fail(h, PIC_EINVAL, "pic_phase_kl: need feq, kl, 1 <= nbins <= 4096, vmax > vmin");
+  if (!h->has_state) return fail(h, PIC_ESTATE, "pic_phase_kl: call pic_reset first");
+  HIPCHK(h, hipSetDevice(h->cfg.device_id));
+  const int E = h->cfg.num_envs, nb2 = nbins * nbins;
+  unsigned* d = nullptr;
+  double* df = nullptr;
+  hipError_t e = phase_counts(h, nbins, vmin, vmax, &d);
+  if (e == hipSuccess) e = hipMalloc((void**)&df, ((size_t)nb2 + E) * sizeof(double));
+  if (e == hipSuccess) e = hipMemcpyAsync(df, feq, (size_t)nb2 * sizeof(double), hipMemcpyHostToDevice, h->stream);
+  if (e == hipSuccess) {
+    const double dx = h->cfg.L / nbins, dv = (vmax - vmin) / nbins;
+    const double norm = h->cfg.n0 / dx / dv / (double)h->cfg.N;                      // objective.py:12, left to right
+    hipLaunchKernelGGL(phase_kl_kernel, dim3(E), dim3(BLOCK), 0, h->stream, d, df, df + nb2, nb2, norm, dx * dv);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(kl, df + nb2, (size_t)E * sizeof(double), hipMemcpyDeviceToHost, h->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+  if (d) hipFree(d);
+  if (df) hipFree(df);
+  if (e != hipSuccess) return fail(h, PIC_EHIP, std::string("pic_phase_kl: ") + hipGetErrorString(e));
   return PIC_OK;
 }
 

@@ -21,7 +21,8 @@ class _DeviceView:
 class BatchedPIC:
     def __init__(self, num_envs: int, N: int, N_mesh: int, n0: float = 1.0, L: float = 50.0, dt: float = 0.1,
                  gamma: float = 5.0, interpol: str = "CIC", device: int = 0, dtype="float64", accum_dtype=None,
-                 blocks_per_env: int = 0, verbose: bool = False, env_index_base: int = 0, position_dtype=None):
+                 blocks_per_env: int = 0, verbose: bool = False, env_index_base: int = 0, position_dtype=None,
+                 placement: str = "auto"):
         self.num_envs, self.N, self.N_mesh = int(num_envs), int(N), int(N_mesh)
         self.n0, self.L, self.gamma, self.interpol = n0, L, gamma, interpol
         self.dx = L / N_mesh
@@ -34,7 +35,7 @@ class BatchedPIC:
         self.device = device
         self.dtype = np.dtype(dtype)
         self._h = _abi.Handle(self.N, self.N_mesh, self.num_envs, L, n0, self.dt, gamma, self.dtype, accum_dtype,
-                              interpol, device, blocks_per_env, env_index_base, position_dtype)
+                              interpol, device, blocks_per_env, env_index_base, position_dtype, placement)
         self.fixed_positions = self._h.fixed_positions
 
     # reset(x0, v0): x0, v0 are [num_envs, N] with any velocity perturbation already applied
@@ -119,6 +120,38 @@ class BatchedPIC:
     def step_actions_device(self, actions_ptr, nsteps: int = 1):
         self._h.step_actions_device(actions_ptr, nsteps)
 
+    def step_actions_traj(self, actions, history: bool = False):
+        """A rollout with a new action every step in ONE call (pic_step_actions_traj): actions
+        [nsteps, num_envs, 2*max_mode]; step s runs under actions[s] -- the inner loop of the trainers
+        (src/control/rl/ddpg.py:421-468) once the actions are known.  history=True -> (KE, PE, PE_reward), each
+        [nsteps, num_envs], after every step; otherwise asynchronous."""
+        return self._h.step_actions_traj(actions, history)
+
+    def step_actions_traj_torch(self, actions):
+        """The same from a float64 CUDA tensor [nsteps, num_envs, 2*max_mode], consumed in stream order."""
+        if not (actions.is_cuda and actions.dtype.is_floating_point and actions.element_size() == 8 and actions.is_contiguous()
+                and actions.dim() == 3 and tuple(actions.shape[1:]) == (self.num_envs, 2 * self.max_mode)):
+            raise ValueError("actions must be a contiguous float64 CUDA tensor [nsteps, num_envs, 2*max_mode]")
+        shared = getattr(self, "_torch_stream", None) is not None
+        if not shared:
+            import torch
+            torch.cuda.current_stream(self.device).synchronize()
+        self._h.step_actions_traj_device(actions.data_ptr(), int(actions.shape[0]))
+        if not shared:
+            self._h.sync()
+
+    def step_ext_traj(self, E_ext_traj, history: bool = False, snapshots: bool = False):
+        """PIC.simulate's E_external_traj (pic.py:175-223) for every environment in one call: E_ext_traj
+        [nsteps, num_envs, N_mesh]; step s runs under E_ext_traj[s]."""
+        return self._h.step_ext_traj(E_ext_traj, history, snapshots)
+
+    def step_feedback(self, nsteps: int, actions: bool = False, history: bool = False):
+        """nsteps iterations of run_feedback.py:130-168's loop body on the device (pic_step_feedback): before each step the
+        actuator coefficients become (-Re E_k, +Im E_k), k = 1..max_mode, of the current E_mesh.  Bit for bit the host loop
+        `step_actions(feedback_actions(max_mode))`.  Returns a dict with "actions" [nsteps, num_envs, 2*max_mode] and / or
+        "KE", "PE", "PE_reward" [nsteps, num_envs] as asked for (None, and asynchronous, with neither)."""
+        return self._h.step_feedback(nsteps, actions, history)
+
     def modes(self, max_mode: int):
         """Complex [num_envs, max_mode]: rows 1..max_mode of compute_E_k_spectrum for the current E_mesh."""
         return self._h.modes(max_mode)
@@ -169,12 +202,20 @@ class BatchedPIC:
             self._h.sync()
         return torch.cat([-re, im], dim=1)
 
-    def rewards_torch(self):
-        """max(1 - PE_reward, 0) per environment as a CUDA tensor (reward.py:72), read from the zero-copy view."""
-        import torch
+    def _ordered_views(self):
+        """The zero-copy views, safe to read on torch's current stream: on a shared stream (use_torch_stream) the stream
+        orders the read behind the steps; otherwise the handle's own stream is drained first."""
         if not hasattr(self, "_views"):
             self._views = self.torch_views()
-        return torch.clamp(1.0 - self._views["PE_reward"], min=0.0)
+        if getattr(self, "_torch_stream", None) is None:
+            self._h.sync()
+        return self._views
+
+    def rewards_torch(self):
+        """max(1 - PE_reward, 0) per environment as a CUDA tensor (reward.py:72), read from the zero-copy view (after a
+        sync of the handle's stream unless it is shared with torch: use_torch_stream)."""
+        import torch
+        return torch.clamp(1.0 - self._ordered_views()["PE_reward"], min=0.0)
 
     def trainer_rewards_torch(self, actions=None, alpha: float = 1.0, beta: float = 1.0, r_pe_n: float = 1.0,
                               r_ie_n: Optional[float] = None):
@@ -184,9 +225,7 @@ class BatchedPIC:
         [num_envs, A] CUDA tensor about to be applied.  r_ie_n defaults to the reference's normaliser, the input energy of
         an all-ones action of the same length (reward.py:26)."""
         import torch
-        if not hasattr(self, "_views"):
-            self._views = self.torch_views()
-        r = alpha * torch.clamp(1.0 - self._views["PE_reward"] / r_pe_n, min=0.0)
+        r = alpha * torch.clamp(1.0 - self._ordered_views()["PE_reward"] / r_pe_n, min=0.0)
         if actions is not None and beta != 0.0:
             a = actions.to(torch.float64)
             ie = (a * a).sum(dim=1) * (self.L * 0.25)
@@ -204,12 +243,9 @@ class BatchedPIC:
         return counts
 
     def kl_divergence(self, feq, vmin: float = -25.0, vmax: float = 25.0):
-        """Reward.compute_kl_divergence (reward.py:43-46) per environment against `feq` [nbins, nbins]."""
-        from ..control.reward import estimate_KL_divergence
-        nb = feq.shape[-1]
-        f = self.phase_density(nb, vmin, vmax)
-        return np.array([estimate_KL_divergence(f[e], feq, self.L / nb, (vmax - vmin) / nb)
-                         for e in range(self.num_envs)])
+        """Reward.compute_kl_divergence (reward.py:43-46) of every environment against `feq` [nbins, nbins]: histogram and
+        reduction on the device, one value per environment read back (pic_phase_kl)."""
+        return self._h.phase_kl(feq, vmin, vmax)
 
     def stream_probe(self, repeats=10):
         """GB/s of a read-2-arrays / write-2-arrays copy with the sweeps' grid on this device."""

@@ -271,9 +271,9 @@ class PIC:
         return self._energies()[2]
 
     def simulate(self, E_external_traj: Optional[List[np.ndarray]] = None):
-        """pic.py:175-223: returns snapshot (2N, Nt+1), E (Nt+1,), PE (Nt+1,).  Without a per-step field trajectory the
-        Nt steps run back to back on the device and particles and energies of every step are read back once at the end
-        (pic_step_snapshots), in chunks of at most ~256 MB; with a trajectory each step takes its own field."""
+        """pic.py:175-223: returns snapshot (2N, Nt+1), E (Nt+1,), PE (Nt+1,).  The Nt steps run back to back on the device --
+        under E_external_traj[i] in step i when a trajectory is given (pic_step_ext_traj), else free (pic_step_snapshots) --
+        and particles and energies of every step are read back once at the end, in chunks of at most ~256 MB."""
         Nt = int(np.ceil((self.tmax - self.tmin) / self.dt))
         pos, vel, Es, PEs = [self.x.copy()], [self.v.copy()], [self.get_energy()], [self.get_electric_energy()]
         if E_external_traj is None:
@@ -291,12 +291,21 @@ class PIC:
             self._invalidate()
             self._fields_hidden = False
         else:
-            for i in range(Nt):
-                self.update_state(E_external_traj[i])
-                pos.append(self.x.copy())
-                vel.append(self.v.copy())
-                Es.append(self.get_energy())
-                PEs.append(self.get_electric_energy())
+            # every step under its own field, still back to back on the device (pic_step_ext_traj)
+            h = self._ensure_handle()
+            traj = np.stack([np.asarray(E_external_traj[i], dtype=np.float64).reshape(self.N_mesh) for i in range(Nt)])
+            chunk = max(1, min(Nt, int(256e6 // (2 * self.N * self.dtype.itemsize))))
+            done = 0
+            while done < Nt:
+                k = min(chunk, Nt - done)
+                x, v, ke, pe, _ = h.step_ext_traj(traj[done:done + k, None, :], snapshots=True)
+                pos.append(np.asarray(x[:, 0, :], dtype=np.float64).T)
+                vel.append(np.asarray(v[:, 0, :], dtype=np.float64).T)
+                Es.extend((ke[:, 0] + pe[:, 0]).tolist())
+                PEs.extend(pe[:, 0].tolist())
+                done += k
+            self._invalidate()
+            self._fields_hidden = False
         snapshot = np.concatenate([np.concatenate(pos, axis=1), np.concatenate(vel, axis=1)], axis=0)
         return snapshot, np.array(Es), np.array(PEs)
 

@@ -712,6 +712,21 @@ def test_stream_ordered_torch_loop_matches_host_loop(oc, po, which):
     dev.sync()
 
 
+def test_rewards_torch_is_ordered_behind_the_step_on_the_handles_own_stream(oc, po):
+    """The handle steps on its own stream; rewards_torch() / trainer_rewards_torch() read a zero-copy view on torch's.  Without
+    a shared stream they must order the read themselves (no manual sync by the caller)."""
+    E_, N, Ng, L = 4, 200_000, 128, 50.0
+    env = oc.BatchedPIC(E_, N, Ng, L=L, dt=0.1)
+    env.reset_sampled("two-stream", seed=4)
+    for _ in range(5):
+        env.step(None, 3)                                    # asynchronous: ~0.1 ms of queued work behind this call
+        r = env.rewards_torch().cpu().numpy()
+        tr = env.trainer_rewards_torch(alpha=2.0, beta=0.0).cpu().numpy()
+        per = env.energies()[2]
+        assert np.array_equal(r, np.maximum(1.0 - per, 0.0)) and np.array_equal(tr, 2.0 * np.maximum(1.0 - per, 0.0))
+    env.close()
+
+
 def test_phase_histogram_and_kl_on_device(oc):
     """estimate_f / compute_kl_divergence with the histogram counted on the device; the
     golden states include values on interior edges, on both outer edges and outside the range."""
@@ -753,6 +768,31 @@ def test_edge_sizes(oc, po):
         env.close()
     with pytest.raises(oc._abi.PicError, match="Ng too large"):
         oc.BatchedPIC(1, 1000, 4096, L=L, dt=0.05)
+
+
+@pytest.mark.parametrize("dtype,ng_sweeps,ng_resident", [("float64", 2722, 1159), ("float32", 3267, 1249)])
+def test_largest_meshes_are_admitted_at_create_or_refused_there(oc, dtype, ng_sweeps, ng_resident):
+    """The LDS budget of a workgroup (64 KB: dynamic meshes + the kernels' static arrays) is checked by pic_create: the largest
+    admitted mesh of either schedule steps, one cell more is EINVAL at create -- never a launch failure later -- and the
+    message quotes the bound that is enforced."""
+    L, N = 50.0, 3000
+    rng = np.random.default_rng(ng_sweeps)
+    x0, v0 = rng.uniform(0, L, (1, N)).astype(dtype), rng.normal(0, 1, (1, N)).astype(dtype)
+    x0[x0 >= L] = 0.0
+    for Ng, bpe in ((ng_sweeps, 2), (ng_resident, -1)):
+        env = oc.BatchedPIC(1, N, Ng, L=L, dt=0.05, dtype=dtype, blocks_per_env=bpe)
+        env.reset(x0, v0)
+        env.step(None, 2)
+        n = env.fields()[0]
+        assert np.allclose(n.sum() * (L / Ng), L, rtol=1e-6 if dtype == "float32" else 1e-12) and env.bad_count() == 0
+        env.close()
+    with pytest.raises(oc._abi.PicError, match=f"at most {ng_sweeps} cells"):
+        oc.BatchedPIC(1, N, ng_sweeps + 1, L=L, dt=0.05, dtype=dtype, blocks_per_env=2)
+    with pytest.raises(oc._abi.PicError, match=f"Ng <= {ng_resident} "):
+        oc.BatchedPIC(1, N, ng_resident + 1, L=L, dt=0.05, dtype=dtype, blocks_per_env=-1)
+    env = oc.BatchedPIC(1, N, ng_resident + 1, L=L, dt=0.05, dtype=dtype)       # automatic choice: the sweeps take it
+    assert env._h.schedule() == "streaming"
+    env.close()
 
 
 def test_many_small_envs(oc, po):
@@ -969,8 +1009,8 @@ def test_placement_search_frees_what_it_does_not_keep(oc):
     state = 2 * 6 * 3_000_000 * 8                                   # 288 MB of float64 x and v
     for _ in range(3):
         env = oc.BatchedPIC(6, 3_000_000, 128, L=50.0, dt=0.1)
-        tried, kept, slowest = env._h.placement_info()
-        assert tried >= 1 and kept >= slowest > 0.0
+        tried, kept, slowest, secs = env._h.placement_info()
+        assert tried >= 1 and kept >= slowest > 0.0 and secs < 0.5
         env.sync()
         held = free0 - torch.cuda.mem_get_info()[0]
         assert state <= held < state + (96 << 20), (held, state)    # particles + meshes + staging, nothing of the search
@@ -980,6 +1020,47 @@ def test_placement_search_frees_what_it_does_not_keep(oc):
         env.close()
     torch.cuda.synchronize()
     assert free0 - torch.cuda.mem_get_info()[0] < 32 << 20
+
+
+def test_placement_off_and_tight_memory(oc):
+    """pic_config.placement = off: no search, nothing timed, x | v in one block -- and the same bits (where the particles lie
+    is not arithmetic).  With little more than the state itself free on the device the search has no room and a handle must
+    still come up."""
+    import torch
+    E_, N, Ng, L = 6, 3_000_000, 128, 50.0
+    runs = {}
+    for mode in ("auto", "off"):
+        env = oc.BatchedPIC(E_, N, Ng, L=L, dt=0.1, placement=mode)
+        info = env._h.placement_info()
+        assert (info[0] >= 1 and info[1] > 0.0) if mode == "auto" else info == (1, 0.0, 0.0, 0.0)
+        env.reset_sampled("bump-on-tail", seed=3)
+        env.step(None, 3)
+        t = env.torch_views()
+        env.sync()
+        runs[mode] = (t["x"].clone(), t["v"].clone(), env.fields())
+        env.close()
+    assert torch.equal(runs["auto"][0], runs["off"][0]) and torch.equal(runs["auto"][1], runs["off"][1])
+    assert all(np.array_equal(p, q) for p, q in zip(runs["auto"][2], runs["off"][2]))
+    # leave about 2.2 x the particle state free (the search may hold a third of what is free: less than one more block)
+    state = 2 * E_ * N * 8
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()                              # (what torch caches would be handed out again without touching the device)
+    free = torch.cuda.mem_get_info()[0]
+    hog, left = [], int(free - 2.2 * state)
+    while left > 0:                                       # in pieces: one 280 GB block is a lot to ask of any allocator
+        piece = min(left, 8 << 30)
+        hog.append(torch.empty(piece, dtype=torch.uint8, device="cuda:0"))
+        left -= piece
+    assert torch.cuda.mem_get_info()[0] < 3 * state
+    env = oc.BatchedPIC(E_, N, Ng, L=L, dt=0.1)
+    env.reset_sampled("bump-on-tail", seed=3)
+    env.step(None, 3)
+    t = env.torch_views()
+    env.sync()
+    assert torch.equal(t["x"], runs["off"][0]) and env.bad_count() == 0
+    env.close()
+    del hog
+    torch.cuda.empty_cache()
 
 
 def test_two_handles_from_two_threads(oc, po):

@@ -100,8 +100,8 @@ def test_header_symbols_are_exported(lib_path):
 
 
 def test_config_struct_layout_matches_header():
-    # int64 N; int32 Ng, num_envs; 4 doubles; 7 int32 (+ 4 bytes of tail padding to the 8-byte alignment)
-    assert ctypes.sizeof(_abi.PicConfig) == 8 + 4 + 4 + 4 * 8 + 7 * 4 + 4
+    # int64 N; int32 Ng, num_envs; 4 doubles; 8 int32
+    assert ctypes.sizeof(_abi.PicConfig) == 8 + 4 + 4 + 4 * 8 + 8 * 4
     hdr = open(os.path.join(ROOT, "include", "picstep.h")).read()
     body = hdr[hdr.index("typedef struct pic_config {"):hdr.index("} pic_config;")]
     fields = re.findall(r"^\s*(?:int64_t|int32_t|double)\s+(\w+);", body, re.M)
@@ -125,23 +125,23 @@ def test_no_cpu_fallback(lib_path):
 
 def test_bad_config_is_rejected(lib_path):
     lib = _abi.load()
-    cfg = _abi.PicConfig(0, 64, 1, 50.0, 1.0, 0.1, 5.0, 0, 0, 0, 0, 0, 0, 0)
+    cfg = _abi.PicConfig(0, 64, 1, 50.0, 1.0, 0.1, 5.0, 0, 0, 0, 0, 0, 0, 0, 0)
     h = ctypes.c_void_p()
     assert lib.pic_create(ctypes.byref(cfg), ctypes.byref(h)) == -1
     assert b"N>=1" in lib.pic_last_error(None)
     A = _abi
-    cfg = A.PicConfig(100, 64, 1, 50.0, 1.0, 0.1, 5.0, A.PIC_F64, 7, 0, 0, 0, 0, 0)                  # no such accumulator
+    cfg = A.PicConfig(100, 64, 1, 50.0, 1.0, 0.1, 5.0, A.PIC_F64, 7, 0, 0, 0, 0, 0, 0)                  # no such accumulator
     assert lib.pic_create(ctypes.byref(cfg), ctypes.byref(h)) == -1
-    cfg = A.PicConfig(100, 64, 1, 50.0, 1.0, 0.1, 5.0, A.PIC_F64, A.PIC_ACC_PACKED, 0, 0, 0, 0, 0)   # packed word, f64 particles
+    cfg = A.PicConfig(100, 64, 1, 50.0, 1.0, 0.1, 5.0, A.PIC_F64, A.PIC_ACC_PACKED, 0, 0, 0, 0, 0, 0)   # packed word, f64 particles
     assert lib.pic_create(ctypes.byref(cfg), ctypes.byref(h)) == -1
     assert b"float32 particles" in lib.pic_last_error(None)
-    cfg = A.PicConfig(100, 64, 1, 50.0, 1.0, 0.1, 5.0, A.PIC_F32, A.PIC_ACC_PACKED, A.PIC_TSC, 0, 0, 0, 0)   # packed word, TSC
+    cfg = A.PicConfig(100, 64, 1, 50.0, 1.0, 0.1, 5.0, A.PIC_F32, A.PIC_ACC_PACKED, A.PIC_TSC, 0, 0, 0, 0, 0)   # packed word, TSC
     assert lib.pic_create(ctypes.byref(cfg), ctypes.byref(h)) == -1
     assert b"CIC only" in lib.pic_last_error(None)
-    cfg = A.PicConfig(100, 64, 1, 50.0, 1.0, 0.1, 5.0, A.PIC_F32, A.PIC_ACC_F64, 0, 0, 0, 0, 0)      # f64 LDS sums, f32 particles
+    cfg = A.PicConfig(100, 64, 1, 50.0, 1.0, 0.1, 5.0, A.PIC_F32, A.PIC_ACC_F64, 0, 0, 0, 0, 0, 0)      # f64 LDS sums, f32 particles
     assert lib.pic_create(ctypes.byref(cfg), ctypes.byref(h)) == -1
     assert b"float64 particles" in lib.pic_last_error(None)
-    cfg = A.PicConfig(100, 64, 1, 50.0, 1.0, 0.1, 5.0, A.PIC_F64, 0, 0, 0, 0, 0, A.PIC_POS_FIXED32)  # fixed-point x, f64 particles
+    cfg = A.PicConfig(100, 64, 1, 50.0, 1.0, 0.1, 5.0, A.PIC_F64, 0, 0, 0, 0, 0, A.PIC_POS_FIXED32, 0)  # fixed-point x, f64 particles
     assert lib.pic_create(ctypes.byref(cfg), ctypes.byref(h)) == -1
     assert b"fixed-point positions" in lib.pic_last_error(None)
     with pytest.raises(ValueError, match="accum_dtype"):
