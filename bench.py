@@ -49,9 +49,11 @@ def synth_bump_on_tail_device(torch, num_envs, N, L, dtype, device, seed, a=0.2,
 
 
 PMC_SUMMARY = "r3_summary.json"          # committed rocprofv3 evidence of this round (profiles/collect.sh)
-# VALU issue ceiling for the resident schedule's roofline: one wave-instruction per SIMD every 2 cycles (the 32-bit rate of a
-# SIMD-32; float64 instructions take 4), 4 SIMDs x 256 CUs at the 2.4 GHz peak clock (MI355X_MICROARCH.md)
-VALU_PEAK_GINST_S = 256 * 4 * 2.4 / 2
+# VALU issue ceiling for the resident schedule's roofline, in 1e9 wave-instructions per second: 256 CUs x 4 SIMDs at the 2.4 GHz
+# peak clock, one wave-instruction per SIMD every 2 cycles for 32-bit operations (a SIMD-32 takes a 64-lane wave in two
+# passes) and every 4 cycles for the float64 operations that make up the float64 push (78.6 TFLOP/s FP64 vector = 16 FMA
+# lanes per SIMD and cycle; MI355X_MICROARCH.md)
+VALU_PEAK_GINST_S = {"float64": 256 * 4 * 2.4 / 4, "float32": 256 * 4 * 2.4 / 2}
 
 
 def pmc_traffic(kernel, args, E, N, Ng):
@@ -331,9 +333,10 @@ def main():
             w, w_src = pmc_valu_per_particle_step(args, N, Ng)
             ach = None if w is None else w * N * E * spl / avg_s / 1e9
             cus = min(E, 256)
-            roof = {"bound": "valu+latency", "kernel": dom, "achieved": ach, "peak": VALU_PEAK_GINST_S, "unit": "Gwave-inst/s",
-                    "frac": None if ach is None else ach / VALU_PEAK_GINST_S,
-                    "frac_of_the_CUs_in_use": None if ach is None else ach / (VALU_PEAK_GINST_S * cus / 256),
+            peak = VALU_PEAK_GINST_S[args.dtype]
+            roof = {"bound": "valu+latency", "kernel": dom, "achieved": ach, "peak": peak, "unit": "Gwave-inst/s",
+                    "frac": None if ach is None else ach / peak,
+                    "frac_of_the_CUs_in_use": None if ach is None else ach / (peak * cus / 256),
                     "traffic": None, "valu_wave_insts_per_particle_step": w, "counter_source": w_src,
                     "avg_launch_ms": avg_s * 1e3, "steps_per_launch": spl,
                     "ms_per_step_with_event_brackets": ms_per_step_events, "measured_inplace_copy_GBs": copy_gbs}

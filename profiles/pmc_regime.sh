@@ -1,5 +1,10 @@
 #!/bin/bash
-# SQ counters of the sweeps (a TA_* group hung rocprofv3 on this pool and was dropped) for one bench.py workload, one rocprofv3 --pmc pass per counter group:
+# SQ counters of the sweeps for one bench.py workload, one rocprofv3 --pmc pass per counter group.
+# Round 2 also tried a TA_* group: rocprofiler_create_counter_config failed with error 38 ("Request exceeds the capabilities of the
+# hardware to collect": more counters of one block than it has slots), rocprofv3 raised SIGABRT at the first dispatch and the
+# process then sat silent until gpurun's 7-minute watchdog killed it (gpurun_out/pmc/env12_g3.err) -- an over-subscribed group, not a
+# hang of the pool.  Groups below stay within 8 SQ counters per pass; every pass runs under its own `timeout`, so an abort cannot
+# sit silent.
 #   bash profiles/pmc_regime.sh <outdir> <tag> [bench args...]      e.g.  ... gpurun_out/pmc env12 --envs 12 --steps 20
 out=$1; tag=$2; shift 2
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -12,7 +17,7 @@ groups=(
 )
 g=0
 for grp in "${groups[@]}"; do
-  rocprofv3 --pmc $grp --output-format csv -d $ROOT/$out/${tag}_g$g -o p -- python3 $ROOT/bench.py --no-cpu-baseline --warmup 2 --profile-steps 0 "$@" > /dev/null 2> $ROOT/$out/${tag}_g$g.err || echo "group $g failed: $(tail -2 $ROOT/$out/${tag}_g$g.err)"
+  timeout -k 10 300 rocprofv3 --pmc $grp --output-format csv -d $ROOT/$out/${tag}_g$g -o p -- python3 $ROOT/bench.py --no-cpu-baseline --warmup 2 --profile-steps 0 "$@" > /dev/null 2> $ROOT/$out/${tag}_g$g.err || echo "group $g failed: $(tail -2 $ROOT/$out/${tag}_g$g.err)"
   g=$((g+1))
 done
 cd $ROOT && python3 - $out $tag <<'PY'

@@ -1,7 +1,8 @@
 """Host-side cost of the reference-style control loop on the reference's own environment size (N = 5000, Ng = 250,
 two-stream): microseconds per iteration for growing slices of what ddpg.py:440-470 does per step."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+# usage: python profiles/pyloop_rl.py [tree]   (tree = an exported copy made by profiles/mk_ab.sh; default: this checkout)
+sys.path.insert(0, os.path.abspath(sys.argv[1]) if len(sys.argv) > 1 else os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import ocplasma_amd
 from ocplasma_amd import PIC, TwoStream, E_field

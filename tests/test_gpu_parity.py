@@ -1045,12 +1045,12 @@ def test_placement_off_and_tight_memory(oc):
     state = 2 * E_ * N * 8
     torch.cuda.synchronize()
     torch.cuda.empty_cache()                              # (what torch caches would be handed out again without touching the device)
-    free = torch.cuda.mem_get_info()[0]
-    hog, left = [], int(free - 2.2 * state)
-    while left > 0:                                       # in pieces: one 280 GB block is a lot to ask of any allocator
-        piece = min(left, 8 << 30)
-        hog.append(torch.empty(piece, dtype=torch.uint8, device="cuda:0"))
-        left -= piece
+    hog = []
+    for _ in range(200):                                  # in pieces: one 280 GB block is a lot to ask of any allocator
+        left = int(torch.cuda.mem_get_info()[0] - 2.2 * state)
+        if left < (64 << 20):
+            break
+        hog.append(torch.empty(min(left, 8 << 30), dtype=torch.uint8, device="cuda:0"))
     assert torch.cuda.mem_get_info()[0] < 3 * state
     env = oc.BatchedPIC(E_, N, Ng, L=L, dt=0.1)
     env.reset_sampled("bump-on-tail", seed=3)
