@@ -169,7 +169,8 @@ def main():
                4: dict(particles=4_000_000, mesh=1024),
                5: dict(envs=128, particles=10_000_000, dtype="float32")}
     for k, val in presets.get(args.config, {}).items():
-        setattr(args, k, val)
+        if getattr(args, k) == ap.get_default(k):          # an explicit flag beside --config wins
+            setattr(args, k, val)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

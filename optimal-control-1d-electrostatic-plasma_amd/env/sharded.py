@@ -18,6 +18,17 @@ def shard_range(rank: int, world: int, total_envs: int):
     return lo, lo + base + (1 if rank < extra else 0)
 
 
+def check_one_device_per_rank(placements):
+    """placements: one (host name, device ordinal) per rank.  Two ranks on one device would step their shards one after the
+    other on the same GPU while the job reports itself as N-way parallel: refuse."""
+    seen = {}
+    for rank, place in enumerate(placements):
+        if place in seen:
+            raise RuntimeError(f"ranks {seen[place]} and {rank} both drive device {place[1]} of host {place[0]}: "
+                               "one rank per GPU (set the device from LOCAL_RANK)")
+        seen[place] = rank
+
+
 class ShardedPIC:
     def __init__(self, total_envs: int, N: int, N_mesh: int, env_factory: Optional[Callable] = None,
                  device: Optional[int] = None, **env_kwargs):
@@ -38,6 +49,13 @@ class ShardedPIC:
                 return BatchedPIC(num_envs, N, N_mesh, **kw)
         if device is not None:
             env_kwargs["device"] = device
+        if dist.is_initialized() and dist.get_backend() == "nccl" and self.world > 1:
+            import socket
+            import torch
+            mine = (socket.gethostname(), int(env_kwargs.get("device", torch.cuda.current_device())))
+            every = [None] * self.world
+            dist.all_gather_object(every, mine)
+            check_one_device_per_rank(every)
         if env_factory_is_default:
             env_kwargs.setdefault("env_index_base", self.lo)      # device sampler keyed by the GLOBAL environment index
         self.env = env_factory(self.num_local, N, N_mesh, **env_kwargs)

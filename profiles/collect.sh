@@ -1,17 +1,14 @@
 #!/bin/bash
 # Collect the judged artifact set on the GPU box (one gpurun call):
-#   bash profiles/collect.sh r2
+#   bash profiles/collect.sh r3
 # writes gpurun_out/<tag>_* and profiles/<tag>_{kernel_stats.csv,summary.json,summary.md}; the other files are copied
 # into profiles/ by hand afterwards (the raw kernel trace is large).
 set -o pipefail
-TAG=${1:-r2}
+TAG=${1:-r3}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-# 1. unprofiled bench line (with the 1-core CPU baseline leg)
-python3 $ROOT/bench.py > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err || exit 1
-echo "bench done"
 # 2. kernel trace + stats of the same command (its own JSON line is kept: the profiled process runs slower)
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_kt -o kt -- python3 $ROOT/bench.py --no-cpu-baseline \
   > $OUT/${TAG}_bench_under_rocprofv3.json 2> $OUT/${TAG}_kt.err || exit 1
@@ -35,6 +32,27 @@ for d in env12 small; do cp "$(ls $OUT/${TAG}_kt_$d/*/*_kernel_stats.csv $OUT/${
 echo "regime traces done"
 cd $ROOT
 cp profiles/${TAG}_kernel_stats.csv profiles/${TAG}_summary.json profiles/${TAG}_summary.md $OUT/ 2>/dev/null
+# 4b. resident schedule: VALU wave-instructions per particle-step (bench.py prices its roofline with them), float64 and fixed32
+cd /tmp
+for fmt in "float64 float" "float32 fixed32"; do set -- $fmt
+  rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES --output-format csv -d $OUT/${TAG}_pmc_res_$1 -o pr -- python3 $ROOT/bench.py --no-cpu-baseline \
+    --steady-steps 0 --profile-steps 0 --envs 256 --particles 5000 --mesh 250 --steps 100 --warmup 100 --dtype $1 --positions $2 > /dev/null 2> $OUT/${TAG}_pmc_res_$1.err \
+    && python3 $ROOT/profiles/resident_valu.py $TAG $OUT/${TAG}_pmc_res_$1 "$1/$2/N=5000/Ng=250" 5000 256 100
+done
+echo "resident pmc done"
+cd $ROOT
+# 1. unprofiled bench line (with the 1-core CPU baseline leg); run after the counter passes so that `roofline.traffic` quotes this
+#    collection's own summary
+python3 $ROOT/bench.py > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err || exit 1
+echo "bench done"
+# 4c. SQ counters of the few-large-environment regime (one environment of N=1e6) and its in-kernel timeline
+bash profiles/pmc_regime.sh gpurun_out/pmc_${TAG} env1 --envs 1 --steps 100 --steady-steps 0 > $OUT/${TAG}_pmc_env1.log 2>&1
+cp gpurun_out/pmc_${TAG}/env1_pmc.md $OUT/${TAG}_pmc_env1.md 2>/dev/null
+python3 profiles/timeline/timeline.py --envs 1 --steps 3 > $OUT/${TAG}_timeline_one_1e6.md 2>/dev/null
+python3 profiles/timeline/timeline.py --envs 4 --steps 3 > $OUT/${TAG}_timeline_four_1e6.md 2>/dev/null
+python3 profiles/timeline/timeline.py --envs 1 --particles 5000 --mesh 250 --steps 1 --calls 4 > $OUT/${TAG}_timeline_res_single.md 2>/dev/null
+python3 profiles/timeline/timeline.py --envs 1 --particles 5000 --mesh 250 --steps 10 --calls 2 > $OUT/${TAG}_timeline_res_ten.md 2>/dev/null
+echo "regime counters and timelines done"
 # 5. the regime table: unprofiled bench lines (HIP-event kernel times) at every BASELINE configuration share and regime
 python3 profiles/regimes.py $OUT/${TAG}_regimes > $OUT/${TAG}_regimes.md 2> $OUT/${TAG}_regimes.err
 # 6. CPU comparators of SURVEY 8d: (a) one core at config 1, (b) one process per core at config 2

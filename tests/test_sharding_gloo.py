@@ -121,3 +121,11 @@ def test_two_rank_sharded_rollout_matches_single_process():
     assert np.allclose(out[0]["energies"], np.stack([ke, pe, per], 1), rtol=1e-13)
     assert np.allclose(out[0]["returns"], ref.rewards(), rtol=1e-13)
     assert out[0]["actions"].any()           # rank 1 really received rank 0's actions
+
+
+def test_two_ranks_on_one_device_are_refused():
+    """Under RCCL every rank must drive a GPU of its own (ShardedPIC checks it at construction); the rule itself is plain data."""
+    from ocplasma_amd.env.sharded import check_one_device_per_rank
+    check_one_device_per_rank([("node", 0), ("node", 1), ("other", 0)])
+    with pytest.raises(RuntimeError, match="ranks 0 and 2 both drive device 0"):
+        check_one_device_per_rank([("node", 0), ("node", 1), ("node", 0)])
