@@ -168,8 +168,9 @@ def main():
                3: dict(envs=128, mesh=512, dtype="float32", positions="fixed32", init="two-stream", actions=3),
                4: dict(particles=4_000_000, mesh=1024),
                5: dict(envs=128, particles=10_000_000, dtype="float32")}
+    explicit = {a.dest for a in ap._actions if any(o in sys.argv for o in a.option_strings)}
     for k, val in presets.get(args.config, {}).items():
-        if getattr(args, k) == ap.get_default(k):          # an explicit flag beside --config wins
+        if k not in explicit:                                # an explicit flag beside --config wins
             setattr(args, k, val)
 
     rank = int(os.environ.get("RANK", "0"))
@@ -251,6 +252,10 @@ def main():
         else:
             env._h.step_actions_traj_device(acts.data_ptr(), k)
 
+    # The copy ceiling of this device for the sweeps' access shape (reported next to the 8 TB/s spec).  Taken BEFORE the steps:
+    # 100 passes over scratch arrays of the state's size, which also leave the GPU at its working clock instead of the idle one
+    # the CPU baseline left it in (the first ~30 steps after an idle GPU run 3-8 % slow).  Every rank does it.
+    copy_gbs = env.stream_probe(100)
     run_steps(args.warmup)
     if cdev != "cpu":
         env.sync()
@@ -308,7 +313,6 @@ def main():
     roof = None
     kernels = {}
     ms_per_step_events = None
-    copy_gbs = env.stream_probe(10) if rank == 0 else None
     psteps = args.steps if args.profile_steps < 0 else args.profile_steps
     if rank == 0 and psteps > 0:
         env.profile(True)

@@ -31,7 +31,6 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_kt_small -o 
 for d in env12 small; do cp "$(ls $OUT/${TAG}_kt_$d/*/*_kernel_stats.csv $OUT/${TAG}_kt_$d/*_kernel_stats.csv 2>/dev/null | head -1)" $OUT/${TAG}_kernel_stats_$d.csv; done
 echo "regime traces done"
 cd $ROOT
-cp profiles/${TAG}_kernel_stats.csv profiles/${TAG}_summary.json profiles/${TAG}_summary.md $OUT/ 2>/dev/null
 # 4b. resident schedule: VALU wave-instructions per particle-step (bench.py prices its roofline with them), float64 and fixed32
 cd /tmp
 for fmt in "float64 float" "float32 fixed32"; do set -- $fmt
@@ -41,6 +40,7 @@ for fmt in "float64 float" "float32 fixed32"; do set -- $fmt
 done
 echo "resident pmc done"
 cd $ROOT
+cp profiles/${TAG}_kernel_stats.csv profiles/${TAG}_summary.json profiles/${TAG}_summary.md $OUT/ 2>/dev/null
 # 1. unprofiled bench line (with the 1-core CPU baseline leg); run after the counter passes so that `roofline.traffic` quotes this
 #    collection's own summary
 python3 $ROOT/bench.py > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err || exit 1
