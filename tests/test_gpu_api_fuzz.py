@@ -3,8 +3,9 @@
 The handle keeps hidden state between calls -- the cached deposit of the next step's first drift, the ring of
 accumulator rows with its clean / retired bookkeeping, an open staged step, which schedule steps the particles -- and
 every entry point may be called in any order the header allows.  Each sequence mixes steps (with and without an
-external field, one or several per call), staged steps, energy histories, resets, particle loads followed by
-refresh / invalidate / nothing, probes in the middle of everything, and checks particles, fields and energies
+external field, one or several per call), controlled rollouts (one action held, a new action or a new mesh field
+every step in one call, the feedback law on the device), staged steps, energy histories, resets, particle loads followed
+by refresh / invalidate / nothing, probes in the middle of everything, and checks particles, fields and energies
 against the oracle (src/env/pic.py:131-146 restated) after every state-changing call.  Mesh sizes are ones for which
 the reference's own periodic solve is regular at L = 50 (it is singular e.g. for Ng = 8, 64, 100: DESIGN.md 2); a one-off
 run of 80 further seeds over ten shapes passed as well (profiles/experiments_r2.md)."""
@@ -68,12 +69,15 @@ def test_random_call_sequences(seed, N, Ng, bpe):
         return None if rng.integers(0, 3) == 0 else 0.1 * rng.normal(size=(E_, Ng))
 
     h = oc._abi.Handle(N, Ng, E_, L, 1.0, dt, blocks_per_env=bpe)
+    M = int(rng.integers(1, 5))
+    act = oc.E_field(L, Ng, M)
+    h.set_actuator(act.basis_cos, act.basis_sin)
     x0, v0 = fresh()
     h.reset(x0, v0)
     m = Model(po, x0, v0, Ng, dt)
     log = [f"schedule={h.schedule()}"]
     for it in range(40):
-        op = int(rng.integers(0, 9))
+        op = int(rng.integers(0, 13))
         if op <= 1:                                  # plain steps, one call
             ext, n = field(), int(rng.integers(1, 4))
             h.step(ext, n)
@@ -128,6 +132,37 @@ def test_random_call_sequences(seed, N, Ng, bpe):
                 assert rel_err(Em[e], Eo) < 1e-8, log
             log.append("probe")
             continue
+        elif op == 9:                                # one action held for n steps (E_field.compute_E on the device)
+            a, n = rng.uniform(-1.25, 1.25, (E_, 2 * M)), int(rng.integers(1, 3))
+            h.step_actions(a, n)
+            m.step(act.compute_E_batched(a), n)
+            log.append(f"actions x{n}")
+        elif op == 10:                               # a new action every step, one call, with the energy record
+            n = int(rng.integers(1, 4))
+            a = rng.uniform(-1.25, 1.25, (n, E_, 2 * M))
+            rec = h.step_actions_traj(a, history=bool(rng.integers(0, 2)))
+            for k in range(n):
+                m.step(act.compute_E_batched(a[k]), 1)
+                if rec is not None:
+                    mke, mpe = m.energies()
+                    assert np.allclose(rec[0][k], mke, rtol=1e-11) and np.allclose(rec[1][k], mpe, rtol=1e-7), log
+            log.append(f"actions_traj x{n}")
+        elif op == 11:                               # a new mesh field every step, one call
+            n = int(rng.integers(1, 4))
+            f = 0.1 * rng.normal(size=(n, E_, Ng))
+            h.step_ext_traj(f)
+            for k in range(n):
+                m.step(f[k], 1)
+            log.append(f"ext_traj x{n}")
+        elif op == 12:                               # the feedback law on the device against the same law on the oracle's field
+            n = int(rng.integers(1, 4))
+            rec = h.step_feedback(n, actions=True)
+            for k in range(n):
+                Ek = np.stack([(np.fft.fft(s_.E_mesh[:, 0]) / Ng * 2.0)[1:M + 1] for s_ in m.sims])
+                a = np.concatenate([-Ek.real, Ek.imag], axis=1)
+                assert np.allclose(rec["actions"][k], a, rtol=1e-7, atol=1e-10), log
+                m.step(act.compute_E_batched(a), 1)
+            log.append(f"feedback x{n}")
         else:                                        # device-sampled reset: take the particles over into the model
             h.reset_sampled("two-stream", seed=int(rng.integers(0, 1000)))
             x0, v0 = h.particles()
