@@ -111,6 +111,19 @@ struct SolveArgs {
   double N_over_L;
 };
 
+// The same in two halves for callers that have other loads to issue in between (S <= 4, which is what pic_create chooses): the
+// request leaves the sub-row values unsummed, so that nothing waits for them before acc_row_finish.
+struct AccRequest { acc_t r[4]; };
+__device__ __forceinline__ AccRequest acc_row_request(const acc_t* __restrict__ row, int j, int S, long long sub) {
+  AccRequest q;                        // four unconditional loads, untouched until acc_row_finish: a sub-row that does not exist
+#pragma unroll                         // re-reads sub-row 0 (loads under a branch, or a select right behind them, would make the
+  for (int s = 0; s < 4; ++s) q.r[s] = row[(size_t)(s < S ? s : 0) * sub + j];       // compiler wait here)
+  return q;
+}
+__device__ __forceinline__ acc_t acc_row_finish(const AccRequest& q, int S) {
+  return (q.r[0] + (S > 1 ? q.r[1] : 0)) + ((S > 2 ? q.r[2] : 0) + (S > 3 ? q.r[3] : 0));
+}
+
 // How the external field of a step's force evaluations is obtained (util.py:102-103 adds it to E_mesh): given on the mesh,
 // or built from actuator coefficients inside the field phase, E_ext = basis_cos @ a[:M] + basis_sin @ a[M:]
 // (src/control/actuator.py:54-63) -- no actuator launch and no mesh-sized array per step.  Pointers are those of environment 0

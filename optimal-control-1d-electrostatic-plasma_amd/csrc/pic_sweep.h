@@ -12,14 +12,17 @@ namespace {
 // step has no field-solve launch between its sweeps.  sb: Ng doubles of LDS scratch.
 // ctl (pointers of THIS environment): the external field on the mesh, or the actuator coefficients it is built from here
 // (xt: Ng doubles of LDS scratch for it) -- a controlled step has no actuator launch either.
+// first: the deposit of node threadIdx.x, requested by the caller BEFORE its particle tile (the solve is what the workgroup
+// waits for first, and a wave's loads return in the order they were issued)
 template <typename T, int OFF>
-__device__ __forceinline__ void prologue_field(const acc_t* __restrict__ acc_in, int S, long long sub, const Control& ctl,
-                                               int Ng, double unit, double scale, double n0, double dx,
+__device__ __forceinline__ void prologue_field(const acc_t* __restrict__ acc_in, acc_t first, int S, long long sub,
+                                               const Control& ctl, int Ng, double unit, double scale, double n0, double dx,
                                                double* __restrict__ sb, double* __restrict__ xt, double* __restrict__ slot,
                                                T* __restrict__ Es) {
   const int tid = threadIdx.x;
-  for (int j = tid; j < Ng; j += BLOCK)
-    sb[j] = ((double)acc_row_sum(acc_in, j, S, sub) * unit) * scale - n0;                   // interpolate.py:16-18, pic.py:116
+  if (tid < Ng) sb[tid] = ((double)first * unit) * scale - n0;                              // interpolate.py:16-18, pic.py:116
+  for (int j = tid + BLOCK; j < Ng; j += BLOCK)
+    sb[j] = ((double)acc_row_sum(acc_in, j, S, sub) * unit) * scale - n0;
   if (ctl.act)
     for (int j = tid; j < Ng; j += BLOCK)
       xt[j] = actuator_field(ctl.basis, ctl.basis + (size_t)Ng * ctl.M, ctl.act, j, ctl.M);  // actuator.py:54-63
@@ -194,17 +197,19 @@ __global__ __launch_bounds__(BLOCK) void sweep_kernel(typename P::X* __restrict_
   const long long step = (long long)BLOCK * VEC;
   // A workgroup owns one contiguous run of `chunk` particles of its environment; a lane streams 16 B of x and
   // 16 B of v per iteration and updates them in place.  The first tile is requested before the prologue, so that
-  // its latency runs under the field solve.
+  // its latency runs under the field solve -- but behind the accumulator row the solve starts from.
   const long long begin = (long long)blk * a.chunk;
   long long end = begin + a.chunk;
   if (end > a.N) end = a.N;
   long long i = begin + (long long)tid * VEC;
-  XV xv = {};
+  AccRequest first_node{};            // the accumulator row goes first: the prologue waits for it, the tile is not needed before the push
+  if (kGather) first_node = acc_row_request(io.acc_in + (size_t)env * Ng, tid < Ng ? tid : Ng - 1, a.S, a.sub);   // (no branch: see acc_row_request)
+  // (unconditional, from a clamped address where the lane has no first tile: the row is padded to 64 elements.  A load under
+  // a branch costs the exact vmcnt bookkeeping, and the prologue would wait for the tile as well as for the row)
+  const long long i_first = (i + VEC <= end) ? i : 0;
+  XV xv = stream_load(reinterpret_cast<const XV*>(xe + i_first));
   VV vv = {};
-  if (i + VEC <= end) {
-    xv = stream_load(reinterpret_cast<const XV*>(xe + i));
-    if (kReadV) vv = stream_load(reinterpret_cast<const VV*>(ve + i));
-  }
+  if (kReadV) vv = stream_load(reinterpret_cast<const VV*>(ve + i_first));
   PIC_STAMP(2);
 
   if (kGather) {
@@ -212,7 +217,7 @@ __global__ __launch_bounds__(BLOCK) void sweep_kernel(typename P::X* __restrict_
     if (ctl.ext) ctl.ext += (size_t)env * Ng;
     if (ctl.act) ctl.act += (size_t)env * 2 * ctl.M;
     // LDS scratch of the prologue: b / G in the first mesh's place, the actuator field in the second's
-    prologue_field<T, OFF>(io.acc_in + (size_t)env * Ng, a.S, a.sub, ctl, Ng, ldexp(1.0, -a.fg), a.scale, a.n0, a.dx,
+    prologue_field<T, OFF>(io.acc_in + (size_t)env * Ng, acc_row_finish(first_node, a.S), a.S, a.sub, ctl, Ng, ldexp(1.0, -a.fg), a.scale, a.n0, a.dx,
                            reinterpret_cast<double*>(smem_raw), reinterpret_cast<double*>(acc2_all), slot, Es);
   }
   for (int c = tid; c < nacc; c += BLOCK) acc_all[c] = A{};

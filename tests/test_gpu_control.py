@@ -198,6 +198,31 @@ def test_pic_simulate_with_a_field_trajectory(oc, po):
     sim.close()
 
 
+@pytest.mark.parametrize("bpe", [-1, 2])
+def test_field_trajectory_with_snapshots_on_both_schedules(oc, po, bpe):
+    """pic_step_ext_traj with the particle snapshots PIC.simulate records (pic.py:175-223), resident (the kernel writes them from
+    its registers) and streaming (a copy kernel after every step): snapshots, energies and the final state equal the loop of
+    single steps."""
+    E_, N, Ng, L, K = 2, 4000, 128, 50.0, 5
+    xs, vs = zip(*[po.synthetic_two_stream(N, L, seed=60 + e) for e in range(E_)])
+    x0, v0 = np.stack(xs), np.stack(vs)
+    fields = 0.05 * np.random.default_rng(8).normal(size=(K, E_, Ng))
+    a = oc.BatchedPIC(E_, N, Ng, L=L, dt=0.1, blocks_per_env=bpe)
+    b = oc.BatchedPIC(E_, N, Ng, L=L, dt=0.1, blocks_per_env=bpe)
+    for env in (a, b):
+        env.reset(x0, v0)
+    sx, sv, ke, pe, per = a.step_ext_traj(fields, snapshots=True)
+    for k in range(K):
+        b.step(fields[k])
+        x, v = b.particles()
+        assert np.array_equal(sx[k], x) and np.array_equal(sv[k], v)
+        kb, pb, rb = b.energies()
+        assert np.array_equal(pe[k], pb) and np.array_equal(per[k], rb) and np.allclose(ke[k], kb, rtol=1e-14)
+    assert _same_bits(a, b)
+    a.close()
+    b.close()
+
+
 def test_sub_rows_of_the_accumulators_do_not_change_a_bit(oc, po):
     """Few large environments spread every accumulator row over several sub-rows (pic_device.h: acc_row_sum); a handle with
     many workgroups per environment (sub-rows) and one with few (a single row) must agree bit for bit, and with the oracle."""
