@@ -48,7 +48,10 @@ struct ResidentEdge {      // entry and exit of a launch
 enum : int { RM_EXT = 1,       // the force evaluations have an external field (rc.xt)
              RM_PER_STEP = 2,  // ... a new one every step (ext_step / act_step)
              RM_FEEDBACK = 4,  // ... computed by the feedback law
-             RM_SNAP = 8 };    // particle snapshots are recorded
+             RM_SNAP = 8,      // particle snapshots are recorded
+             RM_RECORD = 16 }; // something reads the fields and energies BETWEEN the steps of the call (an energy history, the feedback
+                               // law): every step's post-step refresh is made.  Otherwise only the last step's, which is all that
+                               // can be seen afterwards (pic.py:145-146 overwrites them step by step)
 struct ResidentIO {
   int nsteps;
   int num_envs;
@@ -342,7 +345,7 @@ __global__ __launch_bounds__(NW * 64) void resident_kernel(typename P::X* __rest
       A* in = (st == ST_C) ? accB : accA;
       A* out = (st == ST_C) ? accA : accB;
       // (the previous step's post-step refresh goes with sub-stage B's field phase; the last step's follows the loop)
-      if (st == ST_B && step > 0)
+      if (st == ST_B && step > 0 && (mode & RM_RECORD))
         resident_field<T, A, SHAPE, NW, true>(in, R, stride, has_ext, Ng, a.fg, a.scale, a.n0, a.dx, sb, slot, Es, out, nullptr,
                                               mode, num_envs, rc, ke_prev, step - 1);
       else

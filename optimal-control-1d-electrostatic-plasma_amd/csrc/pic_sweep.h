@@ -13,19 +13,19 @@ namespace {
 // ctl (pointers of THIS environment): the external field on the mesh, or the actuator coefficients it is built from here
 // (xt: Ng doubles of LDS scratch for it) -- a controlled step has no actuator launch either.
 // first: the deposit of node threadIdx.x, requested by the caller BEFORE its particle tile (the solve is what the workgroup
-// waits for first, and a wave's loads return in the order they were issued)
+// waits for first, and a wave's loads return in the order they were issued); it is waited for here, behind the actuator product
 template <typename T, int OFF>
-__device__ __forceinline__ void prologue_field(const acc_t* __restrict__ acc_in, acc_t first, int S, long long sub,
+__device__ __forceinline__ void prologue_field(const acc_t* __restrict__ acc_in, const AccRequest& first, int S, long long sub,
                                                const Control& ctl, int Ng, double unit, double scale, double n0, double dx,
                                                double* __restrict__ sb, double* __restrict__ xt, double* __restrict__ slot,
                                                T* __restrict__ Es) {
   const int tid = threadIdx.x;
-  if (tid < Ng) sb[tid] = ((double)first * unit) * scale - n0;                              // interpolate.py:16-18, pic.py:116
-  for (int j = tid + BLOCK; j < Ng; j += BLOCK)
-    sb[j] = ((double)acc_row_sum(acc_in, j, S, sub) * unit) * scale - n0;
   if (ctl.act)
     for (int j = tid; j < Ng; j += BLOCK)
       xt[j] = actuator_field(ctl.basis, ctl.basis + (size_t)Ng * ctl.M, ctl.act, j, ctl.M);  // actuator.py:54-63
+  if (tid < Ng) sb[tid] = ((double)acc_row_finish(first, S) * unit) * scale - n0;           // interpolate.py:16-18, pic.py:116
+  for (int j = tid + BLOCK; j < Ng; j += BLOCK)
+    sb[j] = ((double)acc_row_sum(acc_in, j, S, sub) * unit) * scale - n0;
   __syncthreads();
   PIC_STAMP(3);
   scan_fields(sb, nullptr, Ng, dx, slot);
@@ -168,7 +168,6 @@ __global__ __launch_bounds__(BLOCK) void sweep_kernel(typename P::X* __restrict_
   extern __shared__ __align__(16) unsigned char smem_raw[];
   const int Ng = a.Ng;
   const int stride = Ng + 2;
-  const int nacc = (kDual ? 2 : 1) * a.R * stride;
   A* acc_all = reinterpret_cast<A*>(smem_raw);
   A* acc2_all = acc_all + (size_t)a.R * stride;
   T* Es = reinterpret_cast<T*>(smem_raw + (size_t)2 * a.R * stride * sizeof(A));
@@ -212,21 +211,29 @@ __global__ __launch_bounds__(BLOCK) void sweep_kernel(typename P::X* __restrict_
   if (kReadV) vv = stream_load(reinterpret_cast<const VV*>(ve + i_first));
   PIC_STAMP(2);
 
+  // LDS of the prologue: b / G in the SECOND mesh's place; the first mesh is cleared while the accumulator row is on its way
+  // (with an actuator its field takes that place first).  A sweep that deposits one mesh and has no actuator field to build
+  // goes from the field tile's barrier straight to its particles.
+  bool clear_first = true;
   if (kGather) {
     Control ctl = io.ctl;
     if (ctl.ext) ctl.ext += (size_t)env * Ng;
     if (ctl.act) ctl.act += (size_t)env * 2 * ctl.M;
-    // LDS scratch of the prologue: b / G in the first mesh's place, the actuator field in the second's
-    prologue_field<T, OFF>(io.acc_in + (size_t)env * Ng, acc_row_finish(first_node, a.S), a.S, a.sub, ctl, Ng, ldexp(1.0, -a.fg), a.scale, a.n0, a.dx,
-                           reinterpret_cast<double*>(smem_raw), reinterpret_cast<double*>(acc2_all), slot, Es);
+    else {
+      for (int c = tid; c < a.R * stride; c += BLOCK) acc_all[c] = A{};
+      clear_first = false;
+    }
+    prologue_field<T, OFF>(io.acc_in + (size_t)env * Ng, first_node, a.S, a.sub, ctl, Ng, ldexp(1.0, -a.fg), a.scale, a.n0, a.dx,
+                           reinterpret_cast<double*>(acc2_all), reinterpret_cast<double*>(smem_raw), slot, Es);
   }
-  for (int c = tid; c < nacc; c += BLOCK) acc_all[c] = A{};
+  if (clear_first) for (int c = tid; c < a.R * stride; c += BLOCK) acc_all[c] = A{};
+  if (kDual) for (int c = tid; c < a.R * stride; c += BLOCK) acc2_all[c] = A{};
   if (blk < a.S) {      // workgroup s of an environment clears sub-row s of the retired accumulator rows
     const size_t z = (size_t)blk * a.sub + (size_t)env * Ng;
     if (io.zero0) for (int c = tid; c < Ng; c += BLOCK) io.zero0[z + c] = 0;
     if (io.zero1) for (int c = tid; c < Ng; c += BLOCK) io.zero1[z + c] = 0;
   }
-  __syncthreads();
+  if (clear_first || kDual) __syncthreads();
   PIC_STAMP(6);
 
   const int rep = (tid >> 6) & (a.R - 1);

@@ -369,7 +369,7 @@ void launch_resident(pic_handle* h, const StepControl& sc, int nsteps, double* h
   io.e.q1_out = h->res_q1;
   h->res_q1_valid = true;
   io.mode = (sc.ctl.ext || sc.ctl.act || sc.fb.M > 0 ? RM_EXT : 0) | (sc.ext_step || sc.act_step ? RM_PER_STEP : 0) |
-            (sc.fb.M > 0 ? RM_FEEDBACK : 0) | (snap ? RM_SNAP : 0);
+            (sc.fb.M > 0 ? RM_FEEDBACK : 0) | (snap ? RM_SNAP : 0) | (hist || sc.fb.M > 0 ? RM_RECORD : 0);
   prof_begin(h, 6);
   if (h->fmt == FMT_F64) launch_resident_p<PosF64>(h, io, a);
   else if (h->fmt == FMT_F32) launch_resident_p<PosF32>(h, io, a);

@@ -19,7 +19,7 @@ __device__ __forceinline__ void tl_stamp(int slot) {
   if (slot == 0) tl_l = __builtin_nontemporal_load(&g_tl_launch);
   const int l = tl_l;
   const int wg = blockIdx.y * gridDim.x + blockIdx.x;
-  if (l < TL_LAUNCHES && wg < TL_WGS && slot < TL_SLOTS) {
+  if ((unsigned)l < (unsigned)TL_LAUNCHES && (unsigned)wg < (unsigned)TL_WGS && (unsigned)slot < (unsigned)TL_SLOTS) {   // (unsigned: a kernel without hook 0 reads an unset tl_l)
     g_tl[l][wg][slot] = t;
     if (slot == 0) {
       g_tl[l][wg][1] = __builtin_amdgcn_s_memrealtime();
