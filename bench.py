@@ -144,6 +144,7 @@ def main():
     ap.add_argument("--dtype", default="float64", choices=["float64", "float32"])
     ap.add_argument("--accum", default=None, choices=[None, "fix64", "fixed", "float64"])
     ap.add_argument("--positions", default="float", choices=["float", "fixed32"], help="fixed32: 32-bit fixed-point x (float32)")
+    ap.add_argument("--interpol", default="CIC", choices=["CIC", "TSC"], help="particle shape (the headline workload is CIC)")
     ap.add_argument("--blocks-per-env", type=int, default=0)
     ap.add_argument("--init", default="bump-on-tail", choices=["bump-on-tail", "two-stream"],
                     help="two-stream: BASELINE config 3's ensemble, drawn by the device sampler")
@@ -213,7 +214,7 @@ def main():
     N, Ng, E, L = args.particles, args.mesh, args.envs, 50.0
     tdtype = torch.float64 if args.dtype == "float64" else torch.float32
     env = BatchedPIC(E, N, Ng, L=L, dt=0.1, device=dev_index, dtype=args.dtype, accum_dtype=args.accum,
-                     blocks_per_env=args.blocks_per_env, position_dtype=args.positions)
+                     blocks_per_env=args.blocks_per_env, position_dtype=args.positions, interpol=args.interpol)
     local_rank = dev_index
     if args.init == "two-stream":
         env.reset_sampled("two-stream", v0=3.0, sigma=1.0, A=0.1, n_mode=2, seed=1234 + rank)
@@ -366,7 +367,7 @@ def main():
         "vs_baseline": None, "dtype": "f64" if args.dtype == "float64" else "f32", "data": "synthetic",
         "config": {"workload": f"{'configs[1]: ' if (N, Ng, E, args.dtype) == (1_000_000, 256, 64, 'float64') else ''}"
                                f"{args.init}, N={N}, Ng={Ng}, {E} envs per GPU, {args.dtype}"
-                               f"{' (fixed-point positions)' if args.positions == 'fixed32' else ''}, "
+                               f"{' (fixed-point positions)' if args.positions == 'fixed32' else ''}{', TSC' if args.interpol == 'TSC' else ''}, "
                                + (f"a new random action of {2 * args.actions} coefficients per step through the device actuator "
                                   + ("(one pic_step_actions call per step)" if args.per_step_calls else "(one pic_step_actions_traj call)")
                                   if args.actions > 0 else "no control (E_ext = None)") + ", Yoshida-4 step = PIC.update_state",

@@ -43,6 +43,23 @@ __device__ __forceinline__ T kernarg_at(size_t offset) {
 #endif
 }
 
+// Touch every 64-byte line of the first BYTES of the kernel-argument segment at the kernel's entry, together with the loads the
+// entry makes anyway.  The argument block of a launch is new to the scalar cache; read group by group where they are used
+// (kernarg_at), its lines miss one after the other, each on the critical path of the phase that reads it: the resident kernel,
+// whose step is a chain of short phases, gains 0.45 us per launch from missing them all at once (the sweeps, which read nearly
+// everything at entry anyway, lose 0.1-0.2 us to the longer first wait and do not do it: profiles/experiments_r3.md 12).
+template <int BYTES>
+__device__ __forceinline__ void kernarg_warm() {
+#if defined(__HIP_DEVICE_COMPILE__)
+  using KP = const __attribute__((address_space(4))) unsigned*;
+  KP ka = (KP)__builtin_amdgcn_kernarg_segment_ptr();
+  unsigned w = 0;
+#pragma unroll
+  for (int line = 1; line < (BYTES + 63) / 64; ++line) w |= ka[line * 16];
+  asm volatile("" ::"s"(w));                         // the loads are waited for HERE (one wait for all of them), not sunk to a later block
+#endif
+}
+
 constexpr int BLOCK = 512;          // sweep workgroup: 8 waves of 64 (512 beat 256 by 2.7 % and 128 by 11 % at config 2)
 constexpr int WAVES = BLOCK / 64;
 

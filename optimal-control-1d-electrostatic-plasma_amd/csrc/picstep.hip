@@ -311,12 +311,18 @@ template <typename P, typename A, int SHAPE, int PPT, int NW>
 void launch_resident_t(pic_handle* h, const ResidentIO& io, const SweepArgs& a) {
   // More environments than CUs and a slot count whose lean kernel fits 128 registers: two workgroups per CU beat
   // the 15 % the carried cell / weights save per workgroup (profiles/experiments_r2.md 5).
-  if (h->res_lean)
-    hipLaunchKernelGGL((resident_kernel<P, A, SHAPE, PPT, NW, false>), dim3(h->cfg.num_envs), dim3(NW * 64), h->res_lds,
-                       h->stream, static_cast<typename P::X*>(h->x), static_cast<typename P::V*>(h->v), io, a);
-  else
-    hipLaunchKernelGGL((resident_kernel<P, A, SHAPE, PPT, NW, true>), dim3(h->cfg.num_envs), dim3(NW * 64), h->res_lds,
-                       h->stream, static_cast<typename P::X*>(h->x), static_cast<typename P::V*>(h->v), io, a);
+  // (carrying three TSC weights for 16 particles per lane would need more than 256 registers: that kernel is not even compiled,
+  // pic_create sets res_lean for the shape)
+  constexpr bool kCarryFits = !(SHAPE == PIC_TSC && PPT == 16);
+  if constexpr (kCarryFits) {
+    if (!h->res_lean) {
+      hipLaunchKernelGGL((resident_kernel<P, A, SHAPE, PPT, NW, true>), dim3(h->cfg.num_envs), dim3(NW * 64), h->res_lds,
+                         h->stream, static_cast<typename P::X*>(h->x), static_cast<typename P::V*>(h->v), io, a);
+      return;
+    }
+  }
+  hipLaunchKernelGGL((resident_kernel<P, A, SHAPE, PPT, NW, false>), dim3(h->cfg.num_envs), dim3(NW * 64), h->res_lds,
+                     h->stream, static_cast<typename P::X*>(h->x), static_cast<typename P::V*>(h->v), io, a);
 }
 
 template <typename P, typename A, int SHAPE>

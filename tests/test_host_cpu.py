@@ -99,6 +99,26 @@ def test_header_symbols_are_exported(lib_path):
     assert lib.pic_abi_version() == _abi.ABI_VERSION
 
 
+def test_no_kernel_spills_registers(lib_path):
+    """A particle loop that spills runs at a fraction of its speed and computes the same bits: no parity test notices (round 3
+    shipped a float32 x 16-per-lane resident kernel with 1.5 KB of scratch per lane for a while: 114 us per step instead of 16).
+    The build writes the compiler's resource report next to the library; every kernel in it must be scratch-free and the sweeps
+    must keep the registers for eight waves per SIMD."""
+    import json
+    from ocplasma_amd import _build
+    assert os.path.getmtime(_build.RESOURCES) >= os.path.getmtime(lib_path) - 120, "resource report older than the library"
+    rep = json.load(open(_build.RESOURCES))
+    assert len(rep) > 100
+    spilled = {k: v["scratch_bytes_per_lane"] for k, v in rep.items() if v["scratch_bytes_per_lane"]}
+    assert not spilled, spilled
+    for k, v in rep.items():
+        if "sweep_kernel" in k:
+            assert v["vgprs"] <= 64, (k, v)              # 512 VGPRs per SIMD lane / 8 waves
+        m = re.search(r"resident_kernel.*Li(\d+)ELi8ELb([01])E", k)
+        if m:     # the kernel without carried cells shares a CU with a second workgroup up to 10 particles per lane (picstep.hip: res_lean)
+            assert v["vgprs"] <= (128 if m.group(2) == "0" and int(m.group(1)) <= 10 else 256), (k, v)
+
+
 def test_config_struct_layout_matches_header():
     # int64 N; int32 Ng, num_envs; 4 doubles; 8 int32
     assert ctypes.sizeof(_abi.PicConfig) == 8 + 4 + 4 + 4 * 8 + 8 * 4
