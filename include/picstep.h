@@ -217,6 +217,16 @@ int pic_step_ext_traj(pic_handle* h, const double* E_ext_traj, int mem_kind, int
  * pic_step_actions gives. */
 int pic_step_feedback(pic_handle* h, int max_mode, int nsteps, double* actions_out, double* hist);
 
+/* One iteration of a Gym-style loop in ONE call with ONE synchronisation (src/control/rl/ddpg.py:421-468, ppo.py, sac.py:
+ * env.update_state(E) -> next_state = env.get_state() -> reward from the new state's electric energy): nsteps steps under
+ * the given control -- E_ext [num_envs][Ng] on the mesh (util.py:102-103) or actions [num_envs][2*max_mode] actuator
+ * coefficients (pic_step_actions), both host float64, at most one non-NULL -- then the particles (x, v: host [num_envs][N] in the
+ * particle dtype, positions in length units) and the three energies (host [num_envs] each) of the state after them.  Any
+ * output may be NULL.  Same results as pic_step / pic_step_actions followed by pic_get_particles and pic_get_energies,
+ * which cost a synchronisation each (13-23 us of a 63 us iteration at the reference's N = 5000). */
+int pic_step_observe(pic_handle* h, const double* E_ext, const double* actions, int nsteps, void* x, void* v,
+                     double* KE, double* PE, double* PE_reward);
+
 /* Rows 1..max_mode of compute_E_k_spectrum (src/interpret/spectrum.py:16) for the current E_mesh:
  * Ek[m] = fft(E_mesh)[m] / Ng * 2, re / im [num_envs][max_mode] float64 (host or device, any may be
  * NULL).  The feedback / behaviour-cloning action of run_feedback.py:133-135 and

@@ -71,6 +71,7 @@ SIGNATURES = {
     "pic_step_actions_traj": [_vp, _vp, C.c_int, C.c_int, _vp],
     "pic_step_ext_traj": [_vp, _vp, C.c_int, C.c_int, _vp, _vp],
     "pic_step_feedback": [_vp, C.c_int, C.c_int, _vp, _vp],
+    "pic_step_observe": [_vp, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp],
     "pic_get_modes": [_vp, C.c_int, _vp, _vp, C.c_int],
     "pic_phase_histogram": [_vp, C.c_int, C.c_double, C.c_double, _vp],
     "pic_phase_kl": [_vp, C.c_int, C.c_double, C.c_double, _vp, _vp],
@@ -137,7 +138,9 @@ def _ptr(a):
         return None
     if isinstance(a, int):
         return C.c_void_p(a)
-    return a.ctypes.data_as(C.c_void_p)
+    # (ndarray.ctypes costs ~1.5 us per use and a Gym iteration passes nine pointers.  The bare address keeps no reference to
+    # the array: every caller passes a name, or a view of one, that outlives the call)
+    return C.c_void_p(a.__array_interface__["data"][0])
 
 
 class Handle:
@@ -406,6 +409,28 @@ class Handle:
         if hist is not None:
             out.update(KE=hist[:, 0], PE=hist[:, 1], PE_reward=hist[:, 2])
         return out or None
+
+    def step_observe(self, E_ext=None, actions=None, nsteps=1, particles=True, out=None):
+        """One Gym-style iteration in one call with one synchronisation (pic_step_observe): nsteps steps under E_ext
+        [num_envs][Ng] or actions [num_envs][2*max_mode] (or neither), then -> (x, v, KE, PE, PE_reward) of the new state
+        (x, v None with particles=False).  out: (x, v) C-contiguous arrays of num_envs * N elements of the particle dtype each
+        to receive the particles (e.g. the two halves of one observation buffer) instead of fresh ones."""
+        if E_ext is not None:
+            E_ext = np.ascontiguousarray(np.asarray(E_ext, dtype=np.float64).reshape(self.num_envs, self.Ng))
+        if actions is not None:
+            actions = np.ascontiguousarray(np.asarray(actions, dtype=np.float64).reshape(self.num_envs, 2 * self.max_mode))
+        if out is not None:
+            x, v = out
+            for a in (x, v):
+                if a.dtype != self.dtype or a.size != self.num_envs * self.N or not a.flags.c_contiguous:
+                    raise ValueError("out: two C-contiguous arrays of num_envs * N elements of the particle dtype")
+        else:
+            x = np.empty((self.num_envs, self.N), dtype=self.dtype) if particles else None
+            v = np.empty_like(x) if particles else None
+        en = np.empty((3, self.num_envs))
+        self._chk(self.lib.pic_step_observe(self._h, _ptr(E_ext), _ptr(actions), int(nsteps), _ptr(x), _ptr(v),
+                                            _ptr(en[0]), _ptr(en[1]), _ptr(en[2])))
+        return x, v, en[0], en[1], en[2]
 
     def set_stream(self, hip_stream):
         """hip_stream: integer hipStream_t (e.g. torch.cuda.current_stream().cuda_stream; 0 = the default stream)."""

@@ -91,6 +91,28 @@ __global__ __launch_bounds__(BLOCK) void positions_out_kernel(const typename P::
   }
 }
 
+// What a Gym-style loop reads after a step, written by the device itself into PINNED host memory: x | v rows of every environment
+// ([2][num_envs][N] words of W bytes) and the 3 num_envs energies that follow KE in memory.  Behind a 20 us step one more small
+// kernel costs 2.6 us up to the synchronisation, a strided copy command 7 and a second copy for the energies 6 more
+// (profiles/d2h_probe.hip, profiles/gym_breakdown.py).  grid (ceil(N / BLOCK), 2 num_envs).
+template <typename W>
+__global__ __launch_bounds__(BLOCK) void observe_kernel(const W* __restrict__ x, const W* __restrict__ v, long long N, long long ld,
+                                                        int num_envs, W* __restrict__ host_part, const double* __restrict__ energies,
+                                                        double* __restrict__ host_scal) {
+  const int r = blockIdx.y;
+  const W* src = r < num_envs ? x + (size_t)r * ld : v + (size_t)(r - num_envs) * ld;
+  for (long long i = (long long)blockIdx.x * BLOCK + threadIdx.x; i < N; i += (long long)gridDim.x * BLOCK)
+    host_part[(size_t)r * N + i] = src[i];
+  if (host_scal && blockIdx.x == 0 && r == 0)
+    for (int i = threadIdx.x; i < 3 * num_envs; i += BLOCK) host_scal[i] = energies[i];
+}
+
+// A handful of doubles (one environment's action: <= kInlineDoubles) travel to the device inside the argument block of this
+// kernel: 2 us on the stream where a pageable host-to-device copy command costs 6.
+__global__ void inline_doubles_kernel(InlineDoubles blk, double* __restrict__ dst, int n) {
+  if ((int)threadIdx.x < n) dst[threadIdx.x] = blk.v[threadIdx.x];
+}
+
 // particles of the step just finished -> slot `s` of a snapshot array [steps][2][num_envs][N] (floats of the particle dtype)
 template <typename P>
 __global__ __launch_bounds__(BLOCK) void record_particles_kernel(const typename P::X* __restrict__ x,

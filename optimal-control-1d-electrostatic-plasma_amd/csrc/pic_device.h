@@ -21,7 +21,9 @@ namespace {
 #define PIC_STAMP_LOADS(slot) ((void)0)
 #endif
 
-constexpr int kMaxFeedbackModes = 16;   // modes of the on-device feedback law (pic_step_feedback)
+constexpr int kMaxFeedbackModes = 16;
+constexpr int kInlineDoubles = 32;                 // doubles a call's actuator coefficients may number to travel inside the argument block
+struct InlineDoubles { double v[kInlineDoubles]; };   // modes of the on-device feedback law (pic_step_feedback)
 
 // A kernel argument read from the kernel-argument segment at the point of use.  By-value arguments are loaded into scalar
 // registers at the kernel's entry and held until their last use; the rarely used ones (a riding solve's outputs, the control
@@ -40,6 +42,21 @@ __device__ __forceinline__ T kernarg_at(size_t offset) {
 #else
   (void)offset;
   return T{};                                        // (host pass of the single-source compilation: never executed)
+#endif
+}
+
+// A generic pointer to a member of the argument list: small per-call inputs (one action of a Gym-style loop) travel inside the
+// argument block of the kernel that uses them instead of a copy command or a launch of their own in front of it (5-6 us each
+// on the stream of a 22 us step: profiles/gym_breakdown.py).
+template <typename T>
+__device__ __forceinline__ const T* kernarg_ptr(size_t offset) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  using KP = const __attribute__((address_space(4))) char*;
+  KP ka = (KP)__builtin_amdgcn_kernarg_segment_ptr();
+  return (const T*)(const char*)(ka + offset);
+#else
+  (void)offset;
+  return nullptr;
 #endif
 }
 

@@ -49,6 +49,7 @@ enum : int { RM_EXT = 1,       // the force evaluations have an external field (
              RM_PER_STEP = 2,  // ... a new one every step (ext_step / act_step)
              RM_FEEDBACK = 4,  // ... computed by the feedback law
              RM_SNAP = 8,      // particle snapshots are recorded
+             RM_ACT_INLINE = 32, // the (held) actuator coefficients of all environments are in ResidentIO::act_inline, not behind ctl.act
              RM_RECORD = 16 }; // something reads the fields and energies BETWEEN the steps of the call (an energy history, the feedback
                                // law): every step's post-step refresh is made.  Otherwise only the last step's, which is all that
                                // can be seen afterwards (pic.py:145-146 overwrites them step by step)
@@ -61,7 +62,11 @@ struct ResidentIO {
   ResidentOut o;
   ResidentEdge e;
 };
-constexpr size_t kResidentIoOffset = 2 * sizeof(void*);      // resident_kernel(x, v, io, a): io's byte offset in the argument list
+constexpr size_t kResidentIoOffset = 2 * sizeof(void*);      // resident_kernel(x, v, io, a, act_inline): io's byte offset in the argument list
+// ... and that of the last argument, [num_envs][2M] actuator coefficients with RM_ACT_INLINE (read through a pointer into the
+// argument segment, never as a value; behind everything else, so that a launch without it touches none of its lines)
+constexpr size_t kResidentInlineOffset = kResidentIoOffset + sizeof(ResidentIO) + sizeof(SweepArgs);
+static_assert(sizeof(ResidentIO) % 8 == 0 && sizeof(SweepArgs) % 8 == 0 && alignof(InlineDoubles) == 8, "arguments lie back to back");
 #define RESIDENT_ARG(group, member) kernarg_at<group>(kResidentIoOffset + offsetof(ResidentIO, member))
 
 // What the post-step refresh of a step needs besides the meshes (pic.py:145-146): where its results go, and the LDS
@@ -184,7 +189,7 @@ __device__ __forceinline__ void resident_field(const A* __restrict__ acc_all, in
 
 template <typename P, typename A, int SHAPE, int PPT, int NW, bool kCarry>
 __global__ __launch_bounds__(NW * 64) void resident_kernel(typename P::X* __restrict__ x, typename P::V* __restrict__ v,
-                                                           ResidentIO io, SweepArgs a) {
+                                                           ResidentIO io, SweepArgs a, InlineDoubles act_inline) {
   constexpr int NT = NW * 64;
   using T = typename P::W;
   using X = typename P::X;
@@ -277,9 +282,10 @@ __global__ __launch_bounds__(NW * 64) void resident_kernel(typename P::X* __rest
   // the external field of a call that holds it for all its steps: one copy in LDS, made here
   if (has_ext && !(mode & (RM_PER_STEP | RM_FEEDBACK))) {
     const Control ctl = io.c.ctl;                    // (by value: dead after this block)
-    if (ctl.act)
+    const double* act = (mode & RM_ACT_INLINE) ? kernarg_ptr<double>(kResidentInlineOffset) : ctl.act;
+    if (act)
       for (int j = tid; j < Ng; j += NT)
-        xt_lds[j] = actuator_field(ctl.basis, ctl.basis + (size_t)Ng * ctl.M, ctl.act + (size_t)env * 2 * ctl.M, j, ctl.M);
+        xt_lds[j] = actuator_field(ctl.basis, ctl.basis + (size_t)Ng * ctl.M, act + (size_t)env * 2 * ctl.M, j, ctl.M);
     else
       for (int j = tid; j < Ng; j += NT) xt_lds[j] = ctl.ext[row + j];
   }
@@ -430,14 +436,25 @@ __global__ __launch_bounds__(NW * 64) void resident_kernel(typename P::X* __rest
       const ResidentEdge e = RESIDENT_ARG(ResidentEdge, e);
       F* sx = static_cast<F*>(e.snap) + ((size_t)step * 2 * num_envs + env) * (size_t)a.N;
       F* sv = sx + (size_t)num_envs * (size_t)a.N;
+      // two neighbouring particles per store where the record's row is aligned for it (always with an even N): whole 16- or
+      // 8-byte pieces per lane -- the record may lie in pinned host memory (pic_step_observe), where half-filled lines cost
+      typedef F FPair __attribute__((ext_vector_type(2)));
+      const bool paired = (((size_t)sx | (size_t)sv) & (sizeof(FPair) - 1)) == 0;
+      auto to_length = [&](X q) {
+        F xf = (F)pos_to_length<P>(q, a.L);
+        if (P::kFixed && xf >= (F)a.L) xf = F(0);
+        return xf;
+      };
 #pragma unroll
-      for (int s = 0; s < PPT; ++s) {
-        if (live & (1u << s)) {
-          const long long i = slot_index(s);
-          F xf = (F)pos_to_length<P>(xs[s], a.L);
-          if (P::kFixed && xf >= (F)a.L) xf = F(0);
-          sx[i] = xf;
-          sv[i] = vs[s];
+      for (int g = 0; g < PPT / 2; ++g) {
+        const long long i = slot_index(2 * g);
+        const unsigned both = (live >> (2 * g)) & 3u;
+        if (both == 3u && paired) {
+          *reinterpret_cast<FPair*>(sx + i) = FPair{to_length(xs[2 * g]), to_length(xs[2 * g + 1])};
+          *reinterpret_cast<FPair*>(sv + i) = FPair{vs[2 * g], vs[2 * g + 1]};
+        } else {
+          if (both & 1u) { sx[i] = to_length(xs[2 * g]); sv[i] = vs[2 * g]; }
+          if (both & 2u) { sx[i + 1] = to_length(xs[2 * g + 1]); sv[i + 1] = vs[2 * g + 1]; }
         }
       }
     }

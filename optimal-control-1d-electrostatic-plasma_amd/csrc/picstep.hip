@@ -36,6 +36,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdint>
@@ -308,7 +309,7 @@ void launch_sweep(pic_handle* h, int stage, void* x, void* v, double c_prev, dou
 }
 
 template <typename P, typename A, int SHAPE, int PPT, int NW>
-void launch_resident_t(pic_handle* h, const ResidentIO& io, const SweepArgs& a) {
+void launch_resident_t(pic_handle* h, const ResidentIO& io, const SweepArgs& a, const InlineDoubles& act) {
   // More environments than CUs and a slot count whose lean kernel fits 128 registers: two workgroups per CU beat
   // the 15 % the carried cell / weights save per workgroup (profiles/experiments_r2.md 5).
   // (carrying three TSC weights for 16 particles per lane would need more than 256 registers: that kernel is not even compiled,
@@ -317,32 +318,32 @@ void launch_resident_t(pic_handle* h, const ResidentIO& io, const SweepArgs& a) 
   if constexpr (kCarryFits) {
     if (!h->res_lean) {
       hipLaunchKernelGGL((resident_kernel<P, A, SHAPE, PPT, NW, true>), dim3(h->cfg.num_envs), dim3(NW * 64), h->res_lds,
-                         h->stream, static_cast<typename P::X*>(h->x), static_cast<typename P::V*>(h->v), io, a);
+                         h->stream, static_cast<typename P::X*>(h->x), static_cast<typename P::V*>(h->v), io, a, act);
       return;
     }
   }
   hipLaunchKernelGGL((resident_kernel<P, A, SHAPE, PPT, NW, false>), dim3(h->cfg.num_envs), dim3(NW * 64), h->res_lds,
-                     h->stream, static_cast<typename P::X*>(h->x), static_cast<typename P::V*>(h->v), io, a);
+                     h->stream, static_cast<typename P::X*>(h->x), static_cast<typename P::V*>(h->v), io, a, act);
 }
 
 template <typename P, typename A, int SHAPE>
-void launch_resident_s(pic_handle* h, const ResidentIO& io, const SweepArgs& a) {
+void launch_resident_s(pic_handle* h, const ResidentIO& io, const SweepArgs& a, const InlineDoubles& act) {
   switch (h->res_nw * 100 + h->res_ppt) {
-    case 804: launch_resident_t<P, A, SHAPE, 4, 8>(h, io, a); break;
-    case 808: launch_resident_t<P, A, SHAPE, 8, 8>(h, io, a); break;
-    case 810: launch_resident_t<P, A, SHAPE, 10, 8>(h, io, a); break;
-    default: launch_resident_t<P, A, SHAPE, 16, 8>(h, io, a); break;
+    case 804: launch_resident_t<P, A, SHAPE, 4, 8>(h, io, a, act); break;
+    case 808: launch_resident_t<P, A, SHAPE, 8, 8>(h, io, a, act); break;
+    case 810: launch_resident_t<P, A, SHAPE, 10, 8>(h, io, a, act); break;
+    default: launch_resident_t<P, A, SHAPE, 16, 8>(h, io, a, act); break;
   }
 }
 
 template <typename P>
-void launch_resident_p(pic_handle* h, const ResidentIO& io, const SweepArgs& a) {
+void launch_resident_p(pic_handle* h, const ResidentIO& io, const SweepArgs& a, const InlineDoubles& act) {
   const bool tsc = h->cfg.interpol == PIC_TSC;
   if constexpr (!std::is_same<P, PosF64>::value) {
-    if (h->acc_kind == PIC_ACC_PACKED) { launch_resident_s<P, fix_t, PIC_CIC>(h, io, a); return; }
+    if (h->acc_kind == PIC_ACC_PACKED) { launch_resident_s<P, fix_t, PIC_CIC>(h, io, a, act); return; }
   }
-  if (tsc) launch_resident_s<P, acc_t, PIC_TSC>(h, io, a);
-  else launch_resident_s<P, acc_t, PIC_CIC>(h, io, a);
+  if (tsc) launch_resident_s<P, acc_t, PIC_TSC>(h, io, a, act);
+  else launch_resident_s<P, acc_t, PIC_CIC>(h, io, a, act);
 }
 
 // What drives the external field of the steps of one call (device pointers; see Control / Feedback in pic_device.h)
@@ -351,6 +352,9 @@ struct StepControl {
   long long ext_step = 0;  // elements between consecutive steps' fields / actions (0: held for the whole call)
   long long act_step = 0;
   Feedback fb{};           // fb.M > 0: feedback law; fb.act_hist = device [nsteps][env][2M] record of the actions, or null
+  // one held action of few coefficients, given on the host: inside the resident kernel's own argument block (no copy, no launch)
+  int inline_n = 0;
+  InlineDoubles inline_act{};
 };
 
 // nsteps environment steps in one launch of the resident schedule; hist: device [nsteps][3][env] or null
@@ -374,12 +378,12 @@ void launch_resident(pic_handle* h, const StepControl& sc, int nsteps, double* h
   io.e.q1_in = h->res_q1_valid ? h->res_q1 : nullptr;
   io.e.q1_out = h->res_q1;
   h->res_q1_valid = true;
-  io.mode = (sc.ctl.ext || sc.ctl.act || sc.fb.M > 0 ? RM_EXT : 0) | (sc.ext_step || sc.act_step ? RM_PER_STEP : 0) |
+  io.mode = (sc.inline_n > 0 ? RM_ACT_INLINE : 0) | (sc.ctl.ext || sc.ctl.act || sc.fb.M > 0 ? RM_EXT : 0) | (sc.ext_step || sc.act_step ? RM_PER_STEP : 0) |
             (sc.fb.M > 0 ? RM_FEEDBACK : 0) | (snap ? RM_SNAP : 0) | (hist || sc.fb.M > 0 ? RM_RECORD : 0);
   prof_begin(h, 6);
-  if (h->fmt == FMT_F64) launch_resident_p<PosF64>(h, io, a);
-  else if (h->fmt == FMT_F32) launch_resident_p<PosF32>(h, io, a);
-  else launch_resident_p<PosU32>(h, io, a);
+  if (h->fmt == FMT_F64) launch_resident_p<PosF64>(h, io, a, sc.inline_act);
+  else if (h->fmt == FMT_F32) launch_resident_p<PosF32>(h, io, a, sc.inline_act);
+  else launch_resident_p<PosU32>(h, io, a, sc.inline_act);
   prof_end(h);
 }
 
@@ -1164,14 +1168,47 @@ int pic_step_ext_traj(pic_handle* h, const double* E_ext_traj, int mem_kind, int
   return step_recording(h, sc, nsteps, hist, snap, nullptr, "pic_step_ext_traj");
 }
 
+// x | v rows (and, with scalars, KE | PE | PE_reward) into the pinned staging buffers by a kernel of the handle's stream; the
+// caller synchronises.  Only for handles that have h_part (small states) and float positions.
+static void enqueue_observe(pic_handle* h, bool scalars) {
+  const int E = h->cfg.num_envs;
+  dim3 grid((unsigned)std::min<long long>((h->cfg.N + BLOCK - 1) / BLOCK, 64), 2 * E);
+  if (h->esz == 8)
+    hipLaunchKernelGGL(observe_kernel<double>, grid, dim3(BLOCK), 0, h->stream, static_cast<const double*>(h->x),
+                       static_cast<const double*>(h->v), (long long)h->cfg.N, (long long)h->ld, E, static_cast<double*>(h->h_part),
+                       h->KE, scalars ? h->h_scal : nullptr);
+  else
+    hipLaunchKernelGGL(observe_kernel<float>, grid, dim3(BLOCK), 0, h->stream, static_cast<const float*>(h->x),
+                       static_cast<const float*>(h->v), (long long)h->cfg.N, (long long)h->ld, E, static_cast<float*>(h->h_part),
+                       h->KE, scalars ? h->h_scal : nullptr);
+}
+
+// Actuator coefficients of one call, given on the host, to where the step reads them.  A handful (one environment's action:
+// <= kInlineDoubles) rides in a kernel's argument block -- the resident kernel's own, or a one-wave kernel's in front of the sweeps --
+// where a pageable host-to-device copy command costs 6 us on the stream.
+static int stage_actions(pic_handle* h, const double* actions, StepControl& sc) {
+  const int n = h->cfg.num_envs * 2 * h->act_modes;
+  sc.ctl.act = h->act;
+  if (n <= kInlineDoubles) {
+    std::memcpy(sc.inline_act.v, actions, (size_t)n * sizeof(double));
+    if (h->resident) {
+      sc.inline_n = n;
+      return PIC_OK;
+    }
+    hipLaunchKernelGGL(inline_doubles_kernel, dim3(1), dim3(64), 0, h->stream, sc.inline_act, h->act, n);
+    return PIC_OK;
+  }
+  HIPCHK(h, hipMemcpyAsync(h->act, actions, (size_t)n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  return PIC_OK;
+}
+
 int pic_get_particles(pic_handle* h, void* x, void* v, int mem_kind) {
   if (!h) return PIC_EINVAL;
   HIPCHK(h, hipSetDevice(h->cfg.device_id));
   if (x && v && mem_kind == PIC_HOST && h->h_part && h->fmt != FMT_U32) {
-    // x and v are adjacent on the device: one strided copy of both into pinned memory
+    // small states: a kernel writes both arrays into pinned memory (no copy command: enqueue_observe)
     const size_t row = (size_t)h->cfg.N * h->esz, half = row * h->cfg.num_envs;
-    HIPCHK(h, hipMemcpy2DAsync(h->h_part, row, h->x, (size_t)h->ld * h->esz, row, 2 * (size_t)h->cfg.num_envs,
-                               hipMemcpyDeviceToHost, h->stream));
+    enqueue_observe(h, false);
     HIPCHK(h, hipStreamSynchronize(h->stream));
     std::memcpy(x, h->h_part, half);
     std::memcpy(v, static_cast<char*>(h->h_part) + half, half);
@@ -1409,11 +1446,64 @@ int pic_step_actions(pic_handle* h, const double* actions, int mem_kind, int nst
   if (rc) return rc;
   sc.ctl.act = actions;
   if (mem_kind == PIC_HOST) {
-    HIPCHK(h, hipMemcpyAsync(h->act, actions, (size_t)h->cfg.num_envs * 2 * h->act_modes * sizeof(double), hipMemcpyHostToDevice,
-                             h->stream));
-    sc.ctl.act = h->act;
+    rc = stage_actions(h, actions, sc);
+    if (rc) return rc;
   }
   return advance(h, sc, nsteps, nullptr);
+}
+
+int pic_step_observe(pic_handle* h, const double* E_ext, const double* actions, int nsteps, void* x, void* v, double* KE,
+                     double* PE, double* PE_reward) {
+  if (!h) return PIC_EINVAL;
+  if (E_ext && actions) return fail(h, PIC_EINVAL, "pic_step_observe: E_ext and actions are alternatives");
+  int rc = check_steppable(h, nsteps, "pic_step_observe");
+  if (rc) return rc;
+  HIPCHK(h, hipSetDevice(h->cfg.device_id));
+  StepControl sc;
+  if (actions) {
+    rc = actuator_control(h, sc, "pic_step_observe");
+    if (rc) return rc;
+    rc = stage_actions(h, actions, sc);
+    if (rc) return rc;
+  } else {
+    rc = stage_ext(h, E_ext, PIC_HOST, &sc.ctl.ext);
+    if (rc) return rc;
+  }
+  // Everything the caller reads goes into pinned memory behind the step, then ONE wait.  Small states have pinned staging
+  // (h_part).  A one-step call of the resident schedule needs nothing else: its kernel records the particles after the step
+  // (the snapshot of PIC.simulate, positions in length units whatever their format) and the step's energies (the energy
+  // history) -- both straight into the pinned buffers, whose layouts are those records' for one step.
+  const size_t E = (size_t)h->cfg.num_envs, b = E * sizeof(double);
+  const size_t row = (size_t)h->cfg.N * h->esz, half = row * E;
+  const bool want_part = x || v;
+  bool part_pinned = false;
+  if (h->resident && nsteps == 1 && h->h_part) {
+    rc = advance(h, sc, 1, h->h_scal, want_part ? h->h_part : nullptr);
+    if (rc) return rc;
+    part_pinned = want_part;
+  } else {
+    rc = advance(h, sc, nsteps, nullptr);
+    if (rc) return rc;
+    if (want_part && h->h_part && h->fmt != FMT_U32) {
+      enqueue_observe(h, true);
+      part_pinned = true;
+    } else {
+      HIPCHK(h, hipMemcpyAsync(h->h_scal, h->KE, 3 * b, hipMemcpyDeviceToHost, h->stream));
+      if (x) rc = download_positions(h, x, h->x, PIC_HOST);
+      if (!rc && v) rc = download(h, v, h->v, PIC_HOST);
+      if (rc) return rc;
+    }
+  }
+  HIPCHK(h, hipGetLastError());
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  if (part_pinned) {
+    if (x) std::memcpy(x, h->h_part, half);
+    if (v) std::memcpy(v, static_cast<char*>(h->h_part) + half, half);
+  }
+  if (KE) std::memcpy(KE, h->h_scal, b);
+  if (PE) std::memcpy(PE, h->h_scal + E, b);
+  if (PE_reward) std::memcpy(PE_reward, h->h_scal + 2 * E, b);
+  return PIC_OK;
 }
 
 int pic_step_actions_traj(pic_handle* h, const double* actions, int mem_kind, int nsteps, double* hist) {

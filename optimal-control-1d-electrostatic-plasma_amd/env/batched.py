@@ -117,6 +117,13 @@ class BatchedPIC:
         (actuator.py:54-63) and held for `nsteps` steps."""
         self._h.step_actions(actions, nsteps)
 
+    def step_observe(self, E_external: Optional[np.ndarray] = None, actions: Optional[np.ndarray] = None, nsteps: int = 1):
+        """One iteration of a Gym-style loop for every environment in ONE call with ONE synchronisation (pic_step_observe;
+        ddpg.py:421-468: update_state -> get_state -> reward): nsteps steps under E_external [num_envs, Ng] or actions
+        [num_envs, 2*max_mode] (or neither) -> (state [num_envs, 2N] float64, (KE, PE, PE_reward) each [num_envs])."""
+        x, v, ke, pe, per = self._h.step_observe(E_external, actions, nsteps)
+        return np.concatenate([x, v], axis=1).astype(np.float64), (ke, pe, per)
+
     def step_actions_device(self, actions_ptr, nsteps: int = 1):
         self._h.step_actions_device(actions_ptr, nsteps)
 

@@ -320,30 +320,40 @@ class PIC:
         self._actuator = actuator
         self._actuator_key = None
 
-    def _step_action(self, action):
-        h = self._ensure_handle()
-        if getattr(self, "_actuator_key", None) != id(h):       # a re-created handle needs the tables again
-            h.set_actuator(self._actuator.basis_cos, self._actuator.basis_sin)
-            self._actuator_key = id(h)
-        h.step_actions(np.asarray(action, dtype=np.float64).reshape(1, -1), 1)
-        self._invalidate()
-        self._fields_hidden = False
-
     def step(self, E_external: Optional[np.ndarray] = None):
         """-> (obs, reward, done, info); reward = max(1 - PE_r, 0) of the PRE-step state, i.e. the
         electric-energy term of Reward.compute_reward (src/control/rl/reward.py:72) as the trainers
         evaluate it (ddpg.py:455).  The argument is the mesh field E_external (N_mesh values) or, after
         `set_actuator`, an action of 2*max_mode Fourier coefficients (cos, then sin: actuator.py:54-63)."""
         pe_pre = self.get_reward_electric_energy()
+        h = self._ensure_handle()
         act = getattr(self, "_actuator", None)
+        field = action = None
         if E_external is not None and act is not None and np.size(E_external) == 2 * act.max_mode != self.N_mesh:
-            self._step_action(E_external)
-            ke, pe, per = self._energies()
-            return self.get_state(), max(1.0 - pe_pre, 0.0), False, {"KE": ke, "PE": pe, "PE_reward": per}
-        self.update_state(E_external)
-        ke, pe, per = self._energies()
-        info = {"KE": ke, "PE": pe, "PE_reward": per}
-        return self.get_state(), max(1.0 - pe_pre, 0.0), False, info
+            if getattr(self, "_actuator_key", None) != id(h):       # a re-created handle needs the tables again
+                h.set_actuator(act.basis_cos, act.basis_sin)
+                self._actuator_key = id(h)
+            action = np.asarray(E_external, dtype=np.float64).reshape(1, -1)
+        elif E_external is not None:
+            field = np.asarray(E_external, dtype=np.float64).reshape(-1)
+            if field.shape[0] != self.N_mesh:
+                raise ValueError("E_external must have N_mesh entries")
+        # step, observation and energies in one call with one synchronisation (pic_step_observe)
+        if h.dtype == np.float64:      # the observation is written where it is returned: x | v halves of one fresh (2N, 1) array
+            obs = np.empty((2 * self.N, 1))
+            x, v = obs[:self.N], obs[self.N:]
+            _, _, ke, pe, per = h.step_observe(field, action, 1, out=(x, v))
+        else:
+            x, v, ke, pe, per = h.step_observe(field, action, 1)
+            x, v = x.astype(np.float64).reshape(-1, 1), v.astype(np.float64).reshape(-1, 1)
+            obs = np.concatenate([x, v], axis=0)
+        self._invalidate()
+        self._fields_hidden = False
+        # (x and v are NOT cached from `obs`: the caller owns that array and may normalise it in place; a later read of
+        # PIC.x goes to the device)
+        self._cache["energies"] = (float(ke[0]), float(pe[0]), float(per[0]))
+        info = {"KE": self._cache["energies"][0], "PE": self._cache["energies"][1], "PE_reward": self._cache["energies"][2]}
+        return obs, max(1.0 - pe_pre, 0.0), False, info
 
     def close(self):
         if self._handle is not None:

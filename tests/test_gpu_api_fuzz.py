@@ -4,7 +4,7 @@ The handle keeps hidden state between calls -- the cached deposit of the next st
 accumulator rows with its clean / retired bookkeeping, an open staged step, which schedule steps the particles -- and
 every entry point may be called in any order the header allows.  Each sequence mixes steps (with and without an
 external field, one or several per call), controlled rollouts (one action held, a new action or a new mesh field
-every step in one call, the feedback law on the device), staged steps, energy histories, resets, particle loads followed
+every step in one call, the feedback law on the device, a Gym-style step-and-observe call), staged steps, energy histories, resets, particle loads followed
 by refresh / invalidate / nothing, probes in the middle of everything, and checks particles, fields and energies
 against the oracle (src/env/pic.py:131-146 restated) after every state-changing call.  Mesh sizes are ones for which
 the reference's own periodic solve is regular at L = 50 (it is singular e.g. for Ng = 8, 64, 100: DESIGN.md 2); a one-off
@@ -77,7 +77,7 @@ def test_random_call_sequences(seed, N, Ng, bpe):
     m = Model(po, x0, v0, Ng, dt)
     log = [f"schedule={h.schedule()}"]
     for it in range(40):
-        op = int(rng.integers(0, 13))
+        op = int(rng.integers(0, 14))
         if op <= 1:                                  # plain steps, one call
             ext, n = field(), int(rng.integers(1, 4))
             h.step(ext, n)
@@ -163,6 +163,16 @@ def test_random_call_sequences(seed, N, Ng, bpe):
                 assert np.allclose(rec["actions"][k], a, rtol=1e-7, atol=1e-10), log
                 m.step(act.compute_E_batched(a), 1)
             log.append(f"feedback x{n}")
+        elif op == 13:                               # a Gym-style iteration: step + observation + energies in one call
+            ext, n = field(), int(rng.integers(1, 3))
+            a = rng.uniform(-1.25, 1.25, (E_, 2 * M)) if ext is None and rng.integers(0, 2) else None
+            x, v, ke, pe, per = h.step_observe(ext, a, n)
+            m.step(act.compute_E_batched(a) if a is not None else ext, n)
+            mke, mpe = m.energies()
+            assert np.allclose(ke, mke, rtol=1e-11) and np.allclose(pe, mpe, rtol=1e-7), log
+            for e, s_ in enumerate(m.sims):
+                assert circ_err(x[e], s_.x, L) / L < 1e-11 and rel_err(v[e], s_.v) < 1e-11, log
+            log.append(f"step_observe x{n}")
         else:                                        # device-sampled reset: take the particles over into the model
             h.reset_sampled("two-stream", seed=int(rng.integers(0, 1000)))
             x0, v0 = h.particles()

@@ -245,3 +245,38 @@ def test_sub_rows_of_the_accumulators_do_not_change_a_bit(oc, po):
     assert circ_err(x[0], ref.x, L) / L < 1e-13 and rel_err(v[0], ref.v) < 1e-12 and rel_err(E[0], ref.E_mesh) < 1e-10
     a.close()
     b.close()
+
+
+@pytest.mark.parametrize("N,Ng,bpe,dtype,pos", [(5000, 250, 0, "float64", "float"), (5000, 250, 3, "float64", "float"),
+                                               (3000, 96, 0, "float32", "fixed32"), (300_000, 128, 0, "float64", "float")])
+def test_step_observe_is_the_step_and_its_getters_in_one_call(oc, po, N, Ng, bpe, dtype, pos):
+    """pic_step_observe = update_state + get_state + the energies of the new state in one call with one synchronisation
+    (ddpg.py:421-468): bit for bit what pic_step / pic_step_actions followed by pic_get_particles / pic_get_energies return, under
+    a mesh field, under an action and free, on both schedules, through the pinned staging buffer (small states), the
+    conversion kernel of the fixed-point positions and the pageable path (a state above 4 MB)."""
+    L, E_ = 50.0, 2
+    rng = np.random.default_rng(4)
+    x0 = np.stack([po.synthetic_bump_on_tail(N, L, seed=s)[0] for s in range(E_)])
+    v0 = np.stack([po.synthetic_bump_on_tail(N, L, seed=s)[1] for s in range(E_)])
+    act = oc.E_field(L, Ng, 3)
+    a = oc.BatchedPIC(E_, N, Ng, L=L, dt=0.1, dtype=dtype, position_dtype=pos, blocks_per_env=bpe)
+    b = oc.BatchedPIC(E_, N, Ng, L=L, dt=0.1, dtype=dtype, position_dtype=pos, blocks_per_env=bpe)
+    for env in (a, b):
+        env.set_actuator(act)
+        env.reset(x0, v0)
+    for k in range(6):
+        ext = 0.05 * rng.normal(size=(E_, Ng)) if k % 3 == 1 else None
+        action = rng.uniform(-1.25, 1.25, (E_, 6)) if k % 3 == 2 else None
+        state, (ke, pe, per) = a.step_observe(ext, action, nsteps=1 + k % 2)
+        if action is not None:
+            b.step_actions(action, nsteps=1 + k % 2)
+        else:
+            b.step(ext, nsteps=1 + k % 2)
+        assert np.array_equal(state, b.get_state()), k
+        for got, want in zip((ke, pe, per), b.energies()):
+            assert np.array_equal(got, want), k
+    assert _same_bits(a, b)
+    with pytest.raises(oc._abi.PicError, match="alternatives"):
+        a._h.step_observe(np.zeros((E_, Ng)), np.zeros((E_, 6)))
+    a.close()
+    b.close()
