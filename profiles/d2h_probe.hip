@@ -36,22 +36,26 @@ int main() {
   if (hipHostMalloc(&pinned, 2 * N * sizeof(double), hipHostMallocDefault) != hipSuccess) return 1;
   (void)hipMemset(dev, 0, 2 * ld * sizeof(double));
   (void)hipDeviceSynchronize();
-  const char* names[] = {"2d", "1d x2", "kernel", "none (kernel + sync only)"};
+  const char* names[] = {"2d", "1d x2", "kernel", "none (kernel + sync only)", "kernel, waiting by hipStreamQuery polls", "none, waiting by hipStreamQuery polls"};
   printf("| variant | median us | p10 | p90 | max |\n|---|---|---|---|---|\n");
   for (int round = 0; round < 2; ++round)
-    for (int variant = 0; variant < 4; ++variant) {
+    for (int variant = 0; variant < 6; ++variant) {
       std::vector<double> t(iters);
       for (int it = 0; it < iters; ++it) {
         const auto t0 = std::chrono::steady_clock::now();
-        hipLaunchKernelGGL(busy_kernel, dim3(20), dim3(256), 0, s, dev, N, 2500);
+        hipLaunchKernelGGL(busy_kernel, dim3(20), dim3(256), 0, s, dev, N, 900);
         if (variant == 0)
           (void)hipMemcpy2DAsync(pinned, N * sizeof(double), dev, ld * sizeof(double), N * sizeof(double), 2, hipMemcpyDeviceToHost, s);
         else if (variant == 1) {
           (void)hipMemcpyAsync(pinned, dev, N * sizeof(double), hipMemcpyDeviceToHost, s);
           (void)hipMemcpyAsync(pinned + N, dev + ld, N * sizeof(double), hipMemcpyDeviceToHost, s);
-        } else if (variant == 2)
+        } else if (variant == 2 || variant == 4)
           hipLaunchKernelGGL(pack_kernel, dim3((N + 255) / 256), dim3(256), 0, s, dev, dev + ld, pinned, N);
-        (void)hipStreamSynchronize(s);
+        if (variant >= 4) {
+          while (hipStreamQuery(s) == hipErrorNotReady) {}
+        } else {
+          (void)hipStreamSynchronize(s);
+        }
         t[it] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
       }
       std::sort(t.begin(), t.end());

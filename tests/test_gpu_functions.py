@@ -192,6 +192,12 @@ def test_integration_md_ctypes_stub_runs_verbatim(oc):
     assert rel_err(n, g["n_1"]) < 1e-12 and rel_err(E, g["E_mesh_1"]) < 1e-11
     H, PE, PEr = st.energies()
     assert abs(H / float(g["H"][1]) - 1) < 1e-12
+    a = g["actions"][1]                               # the second golden step through the stub's one-call iteration
+    act.update_E(a[:3], a[3:])
+    obs, H2, PEr2 = st.step(act.compute_E()[:, 0])
+    assert abs(H2 / float(g["H"][2]) - 1) < 1e-12 and abs(PEr2 / float(g["PE_reward"][2]) - 1) < 1e-10
+    x, v = st.fetch()[:2]
+    assert np.array_equal(obs[:RefPIC.N], x) and np.array_equal(obs[RefPIC.N:], v)
 
 
 def test_c_program_drives_the_abi(oc, tmp_path):
