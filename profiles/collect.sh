@@ -1,14 +1,17 @@
 #!/bin/bash
 # Collect the judged artifact set on the GPU box (one gpurun call):
-#   bash profiles/collect.sh r3
+#   bash profiles/collect.sh r3 [a|b]      (a: profiler passes + bench line, b: regime counters, timelines, regime table, CPU legs;
+#                                           nothing = both -- about 20 minutes, more than one gpurun call may take)
 # writes gpurun_out/<tag>_* and profiles/<tag>_{kernel_stats.csv,summary.json,summary.md}; the other files are copied
 # into profiles/ by hand afterwards (the raw kernel trace is large).
 set -o pipefail
 TAG=${1:-r3}
+PART=${2:-ab}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
+if [[ $PART == *a* ]]; then
 # 2. kernel trace + stats of the same command (its own JSON line is kept: the profiled process runs slower)
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_kt -o kt -- python3 $ROOT/bench.py --no-cpu-baseline \
   > $OUT/${TAG}_bench_under_rocprofv3.json 2> $OUT/${TAG}_kt.err || exit 1
@@ -45,6 +48,9 @@ cp profiles/${TAG}_kernel_stats.csv profiles/${TAG}_summary.json profiles/${TAG}
 #    collection's own summary
 python3 $ROOT/bench.py > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err || exit 1
 echo "bench done"
+fi
+if [[ $PART == *b* ]]; then
+cd $ROOT
 # 4c. SQ counters of the few-large-environment regime (one environment of N=1e6) and its in-kernel timeline
 bash profiles/pmc_regime.sh gpurun_out/pmc_${TAG} env1 --envs 1 --steps 100 --steady-steps 0 > $OUT/${TAG}_pmc_env1.log 2>&1
 cp gpurun_out/pmc_${TAG}/env1_pmc.md $OUT/${TAG}_pmc_env1.md 2>/dev/null
@@ -58,4 +64,7 @@ python3 profiles/regimes.py $OUT/${TAG}_regimes > $OUT/${TAG}_regimes.md 2> $OUT
 # 6. CPU comparators of SURVEY 8d: (a) one core at config 1, (b) one process per core at config 2
 python3 bench.py --steps 200 --warmup 20 --envs 1 --particles 10000 --mesh 128 > $OUT/${TAG}_bench_config1.json 2> /dev/null
 python3 bench.py --cpu-procs 16 > $OUT/${TAG}_bench_cpu16.json 2> /dev/null
+python3 profiles/pyloop_rl.py > $OUT/${TAG}_pyloop_rl.log 2> /dev/null
+python3 profiles/gym_breakdown.py > $OUT/${TAG}_gym_breakdown.log 2> /dev/null
+fi
 ls -la $OUT | tail -30

@@ -31,6 +31,9 @@ CASES = [
     ("reference shape x 256, one pic_step_actions call per step (resident)", "--steps 500 --warmup 50 --envs 256 --particles 5000 --mesh 250 --actions 5 --per-step-calls"),
     ("reference shape x 256, sweeps (--blocks-per-env 2)", "--steps 500 --warmup 50 --envs 256 --particles 5000 --mesh 250 --blocks-per-env 2"),
     ("reference shape x 256, fp32 + fixed-point positions (resident)", "--steps 500 --warmup 50 --envs 256 --particles 5000 --mesh 250 --dtype float32 --positions fixed32"),
+    ("64 x N=8000, float32 (resident, 16 particles per lane)", "--steps 500 --warmup 50 --envs 64 --particles 8000 --mesh 250 --dtype float32"),
+    ("64 x N=5000, float32, TSC (resident)", "--steps 500 --warmup 50 --envs 64 --particles 5000 --mesh 250 --dtype float32 --interpol TSC"),
+    ("64 x N=20000, Ng=128, fp64 (sweeps)", "--steps 500 --warmup 50 --envs 64 --particles 20000 --mesh 128"),
 ]
 
 
