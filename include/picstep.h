@@ -269,7 +269,7 @@ int pic_schedule(pic_handle* h);
 /* Particle states of 256 MB and more: x and v are two allocations, and pic_create times a streaming pass over (x, candidate
  * block for v) for a series of candidate blocks: on MI355X two arrays stream together at 6.05 TB/s when they lie in different
  * 32 GiB regions of HBM and at 5.25 TB/s when they share one.  The search stops as soon as the best pair seen is
- * 10 % faster than the slowest seen, after six timed pairs without an improvement, after 100 ms, or when a third of the
+ * 10 % faster than the slowest seen, after fourteen timed pairs (42 GiB, more than a 32 GiB region) without an improvement, after 100 ms, or when a third of the
  * device's free memory is held -- whichever comes first; no absolute rate enters.
  * What a co-resident allocator (torch's caching allocator, another handle on another thread or rank of the same device) sees:
  * while pic_create runs, blocks of the state's size are allocated one after the other and up to a third of the free memory is

@@ -537,8 +537,8 @@ const char* pic_last_error(pic_handle* h) { return h ? h->err.c_str() : g_create
 // For particle states that live in HBM (>= 256 MB) x and v are therefore two allocations: x first, then blocks of the same
 // size one after the other (they are laid down in sequence); every few blocks the pair (x, block) is timed with a streaming
 // pass.  The search is a policy on RATIOS, not on this part's numbers: it ends when the best pair seen streams >= 10 % faster
-// than the slowest one seen (the two kinds have been told apart and we hold a fast one), after six timed pairs without an
-// improvement (all pairs alike on this device: nothing to gain), after 100 ms, or when a third of the free memory is
+// than the slowest one seen (the two kinds have been told apart and we hold a fast one), after fourteen timed pairs without an
+// improvement (42 GiB walked, all pairs alike: nothing to gain on this device), after 100 ms, or when a third of the free memory is
 // held; everything but x and v is freed before pic_create returns.  pic_config.placement = PIC_PLACE_OFF skips it (x | v in
 // one block).  Smaller states keep x | v in one block too (they sit in the Infinity Cache, and the one-copy read-back of
 // pic_get_particles wants them adjacent).
@@ -546,7 +546,8 @@ hipError_t alloc_particles(pic_handle* h, size_t pbytes) {
   constexpr size_t kMinBytes = (size_t)256 << 20;
   constexpr size_t kStride = (size_t)3 << 30;       // memory laid down between two timed candidates (a region is 32 GiB)
   constexpr double kGain = 1.10;                    // best / slowest rate at which the search has found what it looks for
-  constexpr int kPatience = 6;                      // timed pairs without improvement before giving up
+  constexpr int kPatience = 14;                     // timed pairs without improvement before giving up: 14 strides = 42 GiB, more than the
+                                                    // 32 GiB a region spans (6 gave up inside x's own region on some boxes: 1049 instead of 958 us)
   constexpr double kMaxSeconds = 0.100;
   constexpr int kMaxBlocks = 192;
   if (2 * pbytes < kMinBytes || h->cfg.placement == PIC_PLACE_OFF) {

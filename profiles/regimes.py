@@ -10,7 +10,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CASES = [
     ("config 1: N=1e4, Ng=128, 1 env, fp64 (sweeps)", "--config 1 --steps 2000 --warmup 200"),
-    ("config 2: N=1e6, Ng=256, 64 envs, fp64", "--config 2 --steps 100 --warmup 10"),
+    ("config 2: N=1e6, Ng=256, 64 envs, fp64", "--config 2 --steps 200 --warmup 20"),
     ("config 3 as specified: two-stream, N=1e6, Ng=512, 128 envs, fp32 + fixed-point positions, a new random action every step (one pic_step_actions_traj call)", "--config 3 --steps 50 --warmup 5"),
     ("config 3, one pic_step_actions call per step (a trainer's loop)", "--config 3 --steps 50 --warmup 5 --per-step-calls"),
     ("config 3 with float32 positions", "--config 3 --positions float --steps 50 --warmup 5"),

@@ -1004,7 +1004,8 @@ def test_placement_search_frees_what_it_does_not_keep(oc):
     """States of 256 MB and more: pic_create allocates blocks until x and v stream well together and must give
     back every block but the two it keeps, on success and when the handle is destroyed."""
     import torch
-    torch.cuda.synchronize()
+    oc.BatchedPIC(1, 1000, 32, L=50.0, dt=0.1).close()              # (the HIP runtime's one-time allocations behind the first handle
+    torch.cuda.synchronize()                                        # of a process, ~146 MB, are not this test's subject)
     free0 = torch.cuda.mem_get_info()[0]
     state = 2 * 6 * 3_000_000 * 8                                   # 288 MB of float64 x and v
     for _ in range(3):
