@@ -107,12 +107,6 @@ __global__ __launch_bounds__(BLOCK) void observe_kernel(const W* __restrict__ x,
     for (int i = threadIdx.x; i < 3 * num_envs; i += BLOCK) host_scal[i] = energies[i];
 }
 
-// A handful of doubles (one environment's action: <= kInlineDoubles) travel to the device inside the argument block of this
-// kernel: 2 us on the stream where a pageable host-to-device copy command costs 6.
-__global__ void inline_doubles_kernel(InlineDoubles blk, double* __restrict__ dst, int n) {
-  if ((int)threadIdx.x < n) dst[threadIdx.x] = blk.v[threadIdx.x];
-}
-
 // particles of the step just finished -> slot `s` of a snapshot array [steps][2][num_envs][N] (floats of the particle dtype)
 template <typename P>
 __global__ __launch_bounds__(BLOCK) void record_particles_kernel(const typename P::X* __restrict__ x,

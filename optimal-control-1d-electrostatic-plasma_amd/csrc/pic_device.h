@@ -124,6 +124,7 @@ struct SweepArgs {
   int reverse;        // walk environments and chunks from the far end (alternates sweep to sweep)
   int fg;             // fractional bits of the fixed-point accumulators
   int S;              // sub-rows of an accumulator row: workgroup b adds its mesh into sub-row b % S, readers sum the S sub-rows
+  int act_inline;     // sweeps: the actuator coefficients of the call are the kernel's last argument (SweepIO::ctl.act is a stand-in)
   long long sub;      // elements from one sub-row to the next (num_envs * Ng)
   double magic;       // 1.5 * 2^(52 - fg): (w + magic) holds round(w 2^fg) in its low mantissa bits
   double L, dx, rdx, dt;   // rdx = 1/dx (float particles: 1/(float)dx)

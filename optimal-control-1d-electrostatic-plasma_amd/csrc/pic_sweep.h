@@ -149,9 +149,12 @@ struct SweepIO {
   SolveIO post;
 };
 
+constexpr size_t kSweepInlineOffset = 2 * sizeof(void*) + sizeof(SweepIO) + sizeof(SweepArgs);   // sweep_kernel(x, v, io, a, act_inline)
+static_assert(sizeof(SweepIO) % 8 == 0 && sizeof(SweepArgs) % 8 == 0, "arguments lie back to back");
+
 template <typename P, typename A, int SHAPE, int STAGE>
 __global__ __launch_bounds__(BLOCK) void sweep_kernel(typename P::X* __restrict__ x, typename P::V* __restrict__ v,
-                                                      SweepIO io, SweepArgs a) {
+                                                      SweepIO io, SweepArgs a, InlineDoubles act_inline) {
   constexpr int OFF = (SHAPE == PIC_TSC) ? 1 : 0;
   constexpr int VEC = P::VEC;
   using T = typename P::W;
@@ -218,6 +221,9 @@ __global__ __launch_bounds__(BLOCK) void sweep_kernel(typename P::X* __restrict_
   if (kGather) {
     Control ctl = io.ctl;
     if (ctl.ext) ctl.ext += (size_t)env * Ng;
+    // (a.act_inline: the call's actuator coefficients [num_envs][2M] are the kernel's last argument -- read through a pointer
+    // into the argument segment -- instead of an array a copy or a launch in front of the step would have had to fill)
+    if (a.act_inline) ctl.act = kernarg_ptr<double>(kSweepInlineOffset);
     if (ctl.act) ctl.act += (size_t)env * 2 * ctl.M;
     else {
       for (int c = tid; c < a.R * stride; c += BLOCK) acc_all[c] = A{};

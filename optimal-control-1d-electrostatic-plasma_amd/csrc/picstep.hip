@@ -121,6 +121,7 @@ struct pic_handle {
   size_t traj_bytes = 0;
   unsigned long long* res_q1 = nullptr;   // resident schedule: [env][R (Ng + 2)] LDS mesh of the next step's q1 deposit, launch to launch
   bool res_q1_valid = false;
+  const InlineDoubles* inline_act = nullptr;   // streaming schedule, for the duration of a call: the held action rides in the sweeps' argument blocks
   Feedback fb{};                  // feedback outputs wanted from the NEXT post-step solve of the streaming schedule (fb.M = 0: none)
   double* aux_n = nullptr;        // probe outputs
   double* aux_E = nullptr;
@@ -198,8 +199,9 @@ void ring_retire(pic_handle* h, int slot) {
 template <typename P, typename A, int SHAPE, int STAGE>
 void launch_sweep_t(pic_handle* h, const SweepIO& io, void* x, void* v, const SweepArgs& a) {
   dim3 grid(h->nblk + ((STAGE == ST_B && io.post.acc) ? 1 : 0), h->cfg.num_envs);
+  static const InlineDoubles none{};
   hipLaunchKernelGGL((sweep_kernel<P, A, SHAPE, STAGE>), grid, dim3(BLOCK), h->sweep_lds, h->stream,
-                     static_cast<typename P::X*>(x), static_cast<typename P::V*>(v), io, a);
+                     static_cast<typename P::X*>(x), static_cast<typename P::V*>(v), io, a, a.act_inline ? *h->inline_act : none);
 }
 
 template <typename P, typename A, int SHAPE>
@@ -270,6 +272,7 @@ void launch_sweep(pic_handle* h, int stage, void* x, void* v, double c_prev, dou
                   int in_slot, const Control& ctl, acc_t* out, acc_t* out2, int post_slot = -1) {
   SweepArgs a;
   a.N = h->cfg.N; a.ld = h->ld; a.chunk = h->chunk; a.Ng = h->cfg.Ng; a.nblk = h->nblk; a.R = h->R;
+  a.act_inline = (ctl.act && h->inline_act) ? 1 : 0;
   a.reverse = (stage <= ST_D) ? (h->sweep_parity ^= 1) : 0;
   a.fg = h->fg; a.magic = h->magic;
   a.S = h->S; a.sub = (long long)h->cfg.num_envs * h->cfg.Ng;
@@ -997,6 +1000,7 @@ static int advance(pic_handle* h, const StepControl& sc, int nsteps, double* his
     return PIC_OK;
   }
   const size_t act_row = (size_t)E * 2 * sc.ctl.M;
+  h->inline_act = sc.inline_n > 0 ? &sc.inline_act : nullptr;      // (launch_sweep: the held action inside the sweeps' arguments)
   for (int s = 0; s < nsteps; ++s) {
     Control ctl = sc.ctl;
     if (ctl.ext) ctl.ext += (size_t)s * sc.ext_step;
@@ -1024,6 +1028,7 @@ static int advance(pic_handle* h, const StepControl& sc, int nsteps, double* his
   }
   h->hist_row = h->post_hist_row = nullptr;
   h->fb = Feedback{};
+  h->inline_act = nullptr;
   HIPCHK(h, hipGetLastError());
   return PIC_OK;
 }
@@ -1185,18 +1190,14 @@ static void enqueue_observe(pic_handle* h, bool scalars) {
 }
 
 // Actuator coefficients of one call, given on the host, to where the step reads them.  A handful (one environment's action:
-// <= kInlineDoubles) rides in a kernel's argument block -- the resident kernel's own, or a one-wave kernel's in front of the sweeps --
-// where a pageable host-to-device copy command costs 6 us on the stream.
+// <= kInlineDoubles) rides in the argument blocks of the kernels that use it -- the resident kernel's, or the three sweeps' --
+// where a pageable host-to-device copy command, or a launch of its own, costs 5-6 us on the stream in front of the step.
 static int stage_actions(pic_handle* h, const double* actions, StepControl& sc) {
   const int n = h->cfg.num_envs * 2 * h->act_modes;
   sc.ctl.act = h->act;
   if (n <= kInlineDoubles) {
     std::memcpy(sc.inline_act.v, actions, (size_t)n * sizeof(double));
-    if (h->resident) {
-      sc.inline_n = n;
-      return PIC_OK;
-    }
-    hipLaunchKernelGGL(inline_doubles_kernel, dim3(1), dim3(64), 0, h->stream, sc.inline_act, h->act, n);
+    sc.inline_n = n;
     return PIC_OK;
   }
   HIPCHK(h, hipMemcpyAsync(h->act, actions, (size_t)n * sizeof(double), hipMemcpyHostToDevice, h->stream));

@@ -1,21 +1,21 @@
 #!/usr/bin/env python3
 """Where one iteration of a Gym-style loop at the reference's size (N = 5000, Ng = 250, one environment) spends its time,
-layer by layer: raw C ABI calls through ctypes, the Handle methods, PIC.step.   python profiles/gym_breakdown.py [tree]"""
+layer by layer: raw C ABI calls through ctypes, the Handle methods, PIC.step.   python profiles/gym_breakdown.py [N [Ng]]"""
 import os
 import sys
 import time
 
 import numpy as np
 
-tree = os.path.abspath(sys.argv[1]) if len(sys.argv) > 1 else os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tree = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, tree)
 import ocplasma_amd as oc  # noqa: E402
 
-N, Ng, L = 5000, 250, 50.0
+N, Ng, L = (int(sys.argv[1]) if len(sys.argv) > 1 else 5000), (int(sys.argv[2]) if len(sys.argv) > 2 else 250), 50.0
 rng = np.random.default_rng(0)
 
 
-def bench(label, fn, n=3000):
+def bench(label, fn, n=2000):
     for _ in range(200):
         fn()
     t = time.perf_counter()
