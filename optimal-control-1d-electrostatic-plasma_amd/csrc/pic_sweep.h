@@ -16,13 +16,16 @@ namespace {
 // waits for first, and a wave's loads return in the order they were issued); it is waited for here, behind the actuator product
 template <typename T, int OFF>
 __device__ __forceinline__ void prologue_field(const acc_t* __restrict__ acc_in, const AccRequest& first, int S, long long sub,
-                                               const Control& ctl, int Ng, double unit, double scale, double n0, double dx,
-                                               double* __restrict__ sb, double* __restrict__ xt, double* __restrict__ slot,
-                                               T* __restrict__ Es) {
+                                               const Control& ctl, double* __restrict__ ext_out, int Ng, double unit, double scale,
+                                               double n0, double dx, double* __restrict__ sb, double* __restrict__ xt,
+                                               double* __restrict__ slot, T* __restrict__ Es) {
   const int tid = threadIdx.x;
   if (ctl.act)
-    for (int j = tid; j < Ng; j += BLOCK)
-      xt[j] = actuator_field(ctl.basis, ctl.basis + (size_t)Ng * ctl.M, ctl.act, j, ctl.M);  // actuator.py:54-63
+    for (int j = tid; j < Ng; j += BLOCK) {
+      const double e = actuator_field(ctl.basis, ctl.basis + (size_t)Ng * ctl.M, ctl.act, j, ctl.M);   // actuator.py:54-63
+      xt[j] = e;
+      if (ext_out) ext_out[j] = e;
+    }
   if (tid < Ng) sb[tid] = ((double)acc_row_finish(first, S) * unit) * scale - n0;           // interpolate.py:16-18, pic.py:116
   for (int j = tid + BLOCK; j < Ng; j += BLOCK)
     sb[j] = ((double)acc_row_sum(acc_in, j, S, sub) * unit) * scale - n0;
@@ -137,6 +140,12 @@ struct SweepIO {
   // accumulator rows are [S][env][Ng] (S sub-rows, SweepArgs::S; pic_device.h: acc_row_sum)
   const acc_t* acc_in;     // deposit the field of this sweep's gather is solved from (gather stages)
   Control ctl;             // external field of the force evaluation: on the mesh or as actuator coefficients (environment 0's pointers)
+  // The actuator's field is built ONCE per environment and step where the schedule allows it, not in every workgroup of every
+  // sweep: ext_out [env][Ng] (or null) receives, from workgroup 0 of every environment, the field this sweep built from ctl.act
+  // (sweep B of a call's first step: it cannot wait for anyone) or -- with ctl.ext and next_act -- the field of the NEXT step's
+  // coefficients (sweep D inside a rollout).  The sweeps that follow read it as a mesh field (host: run_stages).
+  double* ext_out;
+  const double* next_act;  // [env][2M] coefficients of the next step (environment 0), or null
   acc_t* acc_out;          // receives this sweep's deposit (zero on entry)
   acc_t* acc_out2;         // receives the next step's q1 deposit (dual stages)
   acc_t* zero0;            // accumulators no kernel reads any more: cleared for a later sweep
@@ -229,8 +238,14 @@ __global__ __launch_bounds__(BLOCK) void sweep_kernel(typename P::X* __restrict_
       for (int c = tid; c < a.R * stride; c += BLOCK) acc_all[c] = A{};
       clear_first = false;
     }
-    prologue_field<T, OFF>(io.acc_in + (size_t)env * Ng, first_node, a.S, a.sub, ctl, Ng, ldexp(1.0, -a.fg), a.scale, a.n0, a.dx,
+    prologue_field<T, OFF>(io.acc_in + (size_t)env * Ng, first_node, a.S, a.sub, ctl,
+                           (io.ext_out && blk == 0) ? io.ext_out + (size_t)env * Ng : nullptr, Ng, ldexp(1.0, -a.fg), a.scale, a.n0, a.dx,
                            reinterpret_cast<double*>(acc2_all), reinterpret_cast<double*>(smem_raw), slot, Es);
+  }
+  if (STAGE == ST_D && io.next_act && io.ext_out && blk == 0) {   // (inside a rollout: one workgroup per environment)
+    const Control ctl = io.ctl;
+    for (int j = tid; j < Ng; j += BLOCK)
+      io.ext_out[(size_t)env * Ng + j] = actuator_field(ctl.basis, ctl.basis + (size_t)Ng * ctl.M, io.next_act + (size_t)env * 2 * ctl.M, j, ctl.M);
   }
   if (clear_first) for (int c = tid; c < a.R * stride; c += BLOCK) acc_all[c] = A{};
   if (kDual) for (int c = tid; c < a.R * stride; c += BLOCK) acc2_all[c] = A{};
