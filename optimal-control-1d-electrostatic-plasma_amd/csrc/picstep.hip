@@ -703,6 +703,22 @@ int pic_create(const pic_config* cfg, pic_handle** out) {
     if (small && max_by_work > 64) max_by_work = 64;
     if (nblk > max_by_work) nblk = max_by_work;
     if (nblk < 1) nblk = 1;
+    // A handful of large environments run as one to six workgroups per CU: a total that fills the CUs unevenly leaves some
+    // with one workgroup more than others for the whole sweep (3 x 1e6: 3 x 123 = 369 workgroups on 256 CUs 63.3 us/step, 3 x 163
+    // = 489 58.9).  Take the workgroups per environment from the smallest k >= 2 workgroups per CU that keeps >= 8 tiles' worth
+    // ... per workgroup where it can (k ncu / E, at most the 4-tile count); 1, 2, 4, 6, 8, 12 environments keep what they had.
+    if (!small) {
+      int ncu = 256;
+      hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, cfg->device_id);
+      const long long by4 = (cfg->N + 4 * tile - 1) / (4 * tile);
+      if (nblk * cfg->num_envs < 6ll * ncu) {
+        for (long long k = 2; k <= 6; ++k) {
+          long long c = k * ncu / cfg->num_envs;
+          if (c > by4) c = by4;
+          if (c >= nblk || c == by4) { nblk = c; break; }
+        }
+      }
+    }
   }
   {                                          // a workgroup's chunk of x or v is addressed with 31-bit byte offsets (StreamOut)
     const long long cap = (1ll << 27) - tile;
