@@ -134,7 +134,8 @@ struct pic_handle {
   double* PE = nullptr;
   double* PEr = nullptr;
   double* h_scal = nullptr;       // pinned host staging for KE | PE | PE_reward
-  void* h_part = nullptr;         // pinned host staging for x | v of small states (null for large ones)
+  void* h_part = nullptr;         // pinned host staging for x | v of states up to 64 MB (from pic_create on up to 4 MB, else on first use)
+  bool h_part_refused = false;    // ... could not be had: do not ask again
   unsigned long long* bad = nullptr;
   bool has_state = false;
   // profiling
@@ -810,7 +811,7 @@ int pic_create(const pic_config* cfg, pic_handle** out) {
   // small states (the reference's N = 5000) are read back every step by a Gym-style loop: one copy of x and v
   // together into pinned memory instead of two copies into pageable memory
   if (2 * (size_t)cfg->num_envs * cfg->N * h->esz <= ((size_t)4 << 20))
-    CREATE_CHK(hipHostMalloc(&h->h_part, 2 * (size_t)cfg->num_envs * cfg->N * h->esz, hipHostMallocDefault));
+    CREATE_CHK(hipHostMalloc(&h->h_part, 2 * (size_t)cfg->num_envs * h->ld * h->esz, hipHostMallocDefault));
   CREATE_CHK(hipMalloc((void**)&h->ring, (size_t)(RING + 1) * h->S * gbytes));      // acc_t and double are both 8 bytes
   CREATE_CHK(hipMemsetAsync(h->ring, 0, (size_t)(RING + 1) * h->S * gbytes, h->stream));
   h->probe_acc = ring_row(h, RING);
@@ -1218,10 +1219,42 @@ int pic_step_ext_traj(pic_handle* h, const double* E_ext_traj, int mem_kind, int
   return step_recording(h, sc, nsteps, hist, snap, nullptr, "pic_step_ext_traj");
 }
 
-// x | v rows (and, with scalars, KE | PE | PE_reward) into the pinned staging buffers by a kernel of the handle's stream; the
-// caller synchronises.  Only for handles that have h_part (small states) and float positions.
-static void enqueue_observe(pic_handle* h, bool scalars) {
+// x | v rows (and, with scalars, KE | PE | PE_reward) of float-position handles into the pinned staging buffers; the caller
+// synchronises.  Up to kTinyState bytes a kernel of the handle's stream writes them (a copy command costs 5-7 us of launch
+// latency behind a 20 us step, a kernel that stores to pinned memory 2.6: profiles/d2h_probe.hip); larger states go by copy
+// commands (stores over PCIe run at ~9 GB/s from a kernel, the copy engine at ~50).  The staging for x | v exists from
+// pic_create on for states up to 4 MB and is made here, once, for states up to 64 MB (a vectorised host-side loop over tens
+// of environments: 64 x N = 5000 read back in 0.4 instead of 1.4 ms).
+constexpr size_t kTinyState = (size_t)512 << 10;
+static bool ensure_part_staging(pic_handle* h) {
+  const size_t total = 2 * (size_t)h->cfg.num_envs * h->ld * h->esz;      // rows as they lie on the device (padded to ld)
+  if (!h->h_part && !h->h_part_refused && total <= ((size_t)64 << 20)) {
+    if (hipHostMalloc(&h->h_part, total, hipHostMallocDefault) != hipSuccess) {
+      h->h_part = nullptr;
+      h->h_part_refused = true;
+      (void)hipGetLastError();
+    }
+  }
+  return h->h_part != nullptr;
+}
+// *pitch: bytes from one environment's row to the next in the staging buffer (x rows, then v rows)
+static int enqueue_observe(pic_handle* h, bool scalars, size_t* pitch) {
   const int E = h->cfg.num_envs;
+  const size_t row = (size_t)h->cfg.N * h->esz;
+  *pitch = row;
+  if (2 * row * E > kTinyState) {
+    // the arrays as they lie on the device, padding included, in plain copies (a strided copy command runs at a seventh of the rate)
+    const size_t block = (size_t)E * h->ld * h->esz;
+    *pitch = (size_t)h->ld * h->esz;
+    if (!h->v_separate) {
+      HIPCHK(h, hipMemcpyAsync(h->h_part, h->x, 2 * block, hipMemcpyDeviceToHost, h->stream));
+    } else {
+      HIPCHK(h, hipMemcpyAsync(h->h_part, h->x, block, hipMemcpyDeviceToHost, h->stream));
+      HIPCHK(h, hipMemcpyAsync(static_cast<char*>(h->h_part) + block, h->v, block, hipMemcpyDeviceToHost, h->stream));
+    }
+    if (scalars) HIPCHK(h, hipMemcpyAsync(h->h_scal, h->KE, 3 * (size_t)E * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    return PIC_OK;
+  }
   dim3 grid((unsigned)std::min<long long>((h->cfg.N + BLOCK - 1) / BLOCK, 64), 2 * E);
   if (h->esz == 8)
     hipLaunchKernelGGL(observe_kernel<double>, grid, dim3(BLOCK), 0, h->stream, static_cast<const double*>(h->x),
@@ -1231,6 +1264,22 @@ static void enqueue_observe(pic_handle* h, bool scalars) {
     hipLaunchKernelGGL(observe_kernel<float>, grid, dim3(BLOCK), 0, h->stream, static_cast<const float*>(h->x),
                        static_cast<const float*>(h->v), (long long)h->cfg.N, (long long)h->ld, E, static_cast<float*>(h->h_part),
                        h->KE, scalars ? h->h_scal : nullptr);
+  return PIC_OK;
+}
+// staging -> the caller's [num_envs][N] arrays
+static void unpack_part(pic_handle* h, void* x, void* v, size_t pitch) {
+  const size_t E = (size_t)h->cfg.num_envs, row = (size_t)h->cfg.N * h->esz;
+  const char* sx = static_cast<const char*>(h->h_part);
+  const char* sv = sx + E * pitch;
+  if (pitch == row) {
+    if (x) std::memcpy(x, sx, E * row);
+    if (v) std::memcpy(v, sv, E * row);
+    return;
+  }
+  for (size_t e = 0; e < E; ++e) {
+    if (x) std::memcpy(static_cast<char*>(x) + e * row, sx + e * pitch, row);
+    if (v) std::memcpy(static_cast<char*>(v) + e * row, sv + e * pitch, row);
+  }
 }
 
 // Actuator coefficients of one call, given on the host, to where the step reads them.  A handful (one environment's action:
@@ -1251,13 +1300,13 @@ static int stage_actions(pic_handle* h, const double* actions, StepControl& sc) 
 int pic_get_particles(pic_handle* h, void* x, void* v, int mem_kind) {
   if (!h) return PIC_EINVAL;
   HIPCHK(h, hipSetDevice(h->cfg.device_id));
-  if (x && v && mem_kind == PIC_HOST && h->h_part && h->fmt != FMT_U32) {
-    // small states: a kernel writes both arrays into pinned memory (no copy command: enqueue_observe)
-    const size_t row = (size_t)h->cfg.N * h->esz, half = row * h->cfg.num_envs;
-    enqueue_observe(h, false);
+  if (x && v && mem_kind == PIC_HOST && h->fmt != FMT_U32 && ensure_part_staging(h)) {
+    // states up to 64 MB go through pinned staging (enqueue_observe)
+    size_t pitch = 0;
+    const int rc = enqueue_observe(h, false, &pitch);
+    if (rc) return rc;
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    std::memcpy(x, h->h_part, half);
-    std::memcpy(v, static_cast<char*>(h->h_part) + half, half);
+    unpack_part(h, x, v, pitch);
     return PIC_OK;
   }
   int rc = PIC_OK;
@@ -1523,7 +1572,9 @@ int pic_step_observe(pic_handle* h, const double* E_ext, const double* actions, 
   const size_t row = (size_t)h->cfg.N * h->esz, half = row * E;
   const bool want_part = x || v;
   bool part_pinned = false;
-  if (h->resident && nsteps == 1 && h->h_part) {
+  size_t pitch = row;
+  if (want_part) ensure_part_staging(h);
+  if (h->resident && nsteps == 1 && h->h_part && 2 * half <= kTinyState) {
     rc = advance(h, sc, 1, h->h_scal, want_part ? h->h_part : nullptr);
     if (rc) return rc;
     part_pinned = want_part;
@@ -1531,7 +1582,8 @@ int pic_step_observe(pic_handle* h, const double* E_ext, const double* actions, 
     rc = advance(h, sc, nsteps, nullptr);
     if (rc) return rc;
     if (want_part && h->h_part && h->fmt != FMT_U32) {
-      enqueue_observe(h, true);
+      rc = enqueue_observe(h, true, &pitch);
+      if (rc) return rc;
       part_pinned = true;
     } else {
       HIPCHK(h, hipMemcpyAsync(h->h_scal, h->KE, 3 * b, hipMemcpyDeviceToHost, h->stream));
@@ -1542,10 +1594,7 @@ int pic_step_observe(pic_handle* h, const double* E_ext, const double* actions, 
   }
   HIPCHK(h, hipGetLastError());
   HIPCHK(h, hipStreamSynchronize(h->stream));
-  if (part_pinned) {
-    if (x) std::memcpy(x, h->h_part, half);
-    if (v) std::memcpy(v, static_cast<char*>(h->h_part) + half, half);
-  }
+  if (part_pinned) unpack_part(h, x, v, pitch);
   if (KE) std::memcpy(KE, h->h_scal, b);
   if (PE) std::memcpy(PE, h->h_scal + E, b);
   if (PE_reward) std::memcpy(PE_reward, h->h_scal + 2 * E, b);

@@ -84,7 +84,7 @@ class BatchedPIC:
     def get_state(self):
         """[num_envs, 2N] float64: per environment the reference's get_state() column, flattened."""
         x, v = self._h.particles()
-        return np.concatenate([x, v], axis=1).astype(np.float64)
+        return np.concatenate([x, v], axis=1, dtype=np.float64)
 
     def particles(self):
         return self._h.particles()
@@ -122,7 +122,7 @@ class BatchedPIC:
         ddpg.py:421-468: update_state -> get_state -> reward): nsteps steps under E_external [num_envs, Ng] or actions
         [num_envs, 2*max_mode] (or neither) -> (state [num_envs, 2N] float64, (KE, PE, PE_reward) each [num_envs])."""
         x, v, ke, pe, per = self._h.step_observe(E_external, actions, nsteps)
-        return np.concatenate([x, v], axis=1).astype(np.float64), (ke, pe, per)
+        return np.concatenate([x, v], axis=1, dtype=np.float64), (ke, pe, per)
 
     def step_actions_device(self, actions_ptr, nsteps: int = 1):
         self._h.step_actions_device(actions_ptr, nsteps)
