@@ -107,6 +107,15 @@ __global__ __launch_bounds__(BLOCK) void observe_kernel(const W* __restrict__ x,
     for (int i = threadIdx.x; i < 3 * num_envs; i += BLOCK) host_scal[i] = energies[i];
 }
 
+// n | E_mesh | phi of every environment into pinned host memory (a host-side feedback loop reads E_mesh after every step:
+// run_feedback.py:133; three copy commands into pageable memory cost 25 us behind a 22 us step).  grid (ceil(count / BLOCK), 3).
+__global__ __launch_bounds__(BLOCK) void fields_out_kernel(const double* __restrict__ n, const double* __restrict__ E,
+                                                           const double* __restrict__ phi, double* __restrict__ host, long long count) {
+  const double* src = blockIdx.y == 0 ? n : (blockIdx.y == 1 ? E : phi);
+  for (long long i = (long long)blockIdx.x * BLOCK + threadIdx.x; i < count; i += (long long)gridDim.x * BLOCK)
+    host[(size_t)blockIdx.y * count + i] = src[i];
+}
+
 // particles of the step just finished -> slot `s` of a snapshot array [steps][2][num_envs][N] (floats of the particle dtype)
 template <typename P>
 __global__ __launch_bounds__(BLOCK) void record_particles_kernel(const typename P::X* __restrict__ x,

@@ -136,6 +136,7 @@ struct pic_handle {
   double* h_scal = nullptr;       // pinned host staging for KE | PE | PE_reward
   void* h_part = nullptr;         // pinned host staging for x | v of states up to 64 MB (from pic_create on up to 4 MB, else on first use)
   bool h_part_refused = false;    // ... could not be had: do not ask again
+  double* h_fields = nullptr;     // pinned host staging for n | E_mesh | phi (meshes up to 256 KB each in total), or null
   unsigned long long* bad = nullptr;
   bool has_state = false;
   // profiling
@@ -836,6 +837,7 @@ int pic_create(const pic_config* cfg, pic_handle** out) {
   h->PE = h->KE + cfg->num_envs;
   h->PEr = h->KE + 2 * (size_t)cfg->num_envs;
   CREATE_CHK(hipHostMalloc((void**)&h->h_scal, 3 * sbytes, hipHostMallocDefault));
+  if (gbytes <= ((size_t)256 << 10)) CREATE_CHK(hipHostMalloc((void**)&h->h_fields, 3 * gbytes, hipHostMallocDefault));
   CREATE_CHK(hipMalloc((void**)&h->aux_pe, sbytes));
   CREATE_CHK(hipMemsetAsync(h->aux_pe, 0, sbytes, h->stream));
   CREATE_CHK(hipMalloc((void**)&h->bad, sizeof(unsigned long long)));
@@ -859,6 +861,7 @@ int pic_destroy(pic_handle* h) {
   if (h->v_separate && h->v) hipFree(h->v);
   if (h->h_scal) hipHostFree(h->h_scal);
   if (h->h_part) hipHostFree(h->h_part);
+  if (h->h_fields) hipHostFree(h->h_fields);
   if (h->own_stream) hipStreamDestroy(h->own_stream);
   delete h;
   return PIC_OK;
@@ -1336,6 +1339,17 @@ int pic_get_fields(pic_handle* h, double* n, double* E_mesh, double* phi) {
   if (!h) return PIC_EINVAL;
   HIPCHK(h, hipSetDevice(h->cfg.device_id));
   const size_t gbytes = (size_t)h->cfg.num_envs * h->cfg.Ng * sizeof(double);
+  if (h->h_fields) {                                  // small meshes: one kernel writes all three into pinned memory, one wait
+    const long long count = (long long)h->cfg.num_envs * h->cfg.Ng;
+    hipLaunchKernelGGL(fields_out_kernel, dim3((unsigned)std::min<long long>((count + BLOCK - 1) / BLOCK, 64), 3), dim3(BLOCK), 0,
+                       h->stream, h->n, h->E_mesh, h->phi, h->h_fields, count);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (n) std::memcpy(n, h->h_fields, gbytes);
+    if (E_mesh) std::memcpy(E_mesh, h->h_fields + count, gbytes);
+    if (phi) std::memcpy(phi, h->h_fields + 2 * count, gbytes);
+    return PIC_OK;
+  }
   if (n) HIPCHK(h, hipMemcpyAsync(n, h->n, gbytes, hipMemcpyDeviceToHost, h->stream));
   if (E_mesh) HIPCHK(h, hipMemcpyAsync(E_mesh, h->E_mesh, gbytes, hipMemcpyDeviceToHost, h->stream));
   if (phi) HIPCHK(h, hipMemcpyAsync(phi, h->phi, gbytes, hipMemcpyDeviceToHost, h->stream));

@@ -37,6 +37,15 @@ timed("update_state(None) + get_energy()", lambda k: (sim.update_state(None), si
 timed("host actuator (E_field.compute_E) + update_state(E_ext)", host_field)
 timed("step(action): device actuator + update_state + energies + get_state (Gym tuple)", lambda k: sim.step(actions[k % 4096]))
 timed("update_state(None) + get_state() (2N x 1 host copy)", lambda k: (sim.update_state(None), sim.get_state()))
+
+
+def host_feedback(k):            # run_feedback.py:130-168 on the host: E_mesh read back every step, modes by FFT, actuator, step
+    Ek = np.fft.fft(sim.E_mesh[:, 0]) / Ng * 2.0
+    act.update_E(-Ek[1:M + 1].real, Ek[1:M + 1].imag)
+    sim.update_state(act.compute_E())
+
+
+timed("host feedback loop: E_mesh read back + FFT + E_field.compute_E + update_state(E_ext)", host_feedback)
 h = sim._ensure_handle()
 timed("raw handle: pic_step(NULL, 1) through ctypes", lambda k: h.step(None, 1))
 timed("raw handle: 10 steps per call", lambda k: h.step(None, 10), n=500, warm=50)
