@@ -275,12 +275,13 @@ class Handle:
         self._chk(self.lib.pic_get_cic(self._h, int(env), _ptr(jl), _ptr(jr), _ptr(wl), _ptr(wr)))
         return jl, jr, wl, wr
 
-    def eval_field(self, x, E_ext=None):
-        """compute_E on arbitrary positions -> (n, E_mesh(+E_ext), 0.5*sum(E^2)*dx) per env."""
+    def eval_field(self, x, E_ext=None, fields=True):
+        """compute_E on arbitrary positions -> (n, E_mesh(+E_ext), 0.5*sum(E^2)*dx) per env (n, E_mesh None with fields=False:
+        a caller that wants the energy alone saves two read-backs)."""
         x = self._particles_in(x)
         e = None if E_ext is None else np.ascontiguousarray(np.asarray(E_ext, dtype=np.float64).reshape(self.num_envs, self.Ng))
-        n = np.empty((self.num_envs, self.Ng))
-        E = np.empty_like(n)
+        n = np.empty((self.num_envs, self.Ng)) if fields else None
+        E = np.empty_like(n) if fields else None
         pe = np.empty(self.num_envs)
         self._chk(self.lib.pic_eval_field(self._h, _ptr(x), PIC_HOST, _ptr(e), _ptr(n), _ptr(E), _ptr(pe)))
         return n, E, pe

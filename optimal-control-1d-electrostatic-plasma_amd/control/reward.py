@@ -54,7 +54,7 @@ def estimate_electric_energy(state, E_external, N_mesh, L, n0, device=0):
     state = np.asarray(state, dtype=np.float64).reshape(-1)
     n_part = state.shape[0] // 2
     ext = None if E_external is None else np.asarray(E_external, dtype=np.float64).reshape(1, -1)
-    half_sum = _probe(n_part, N_mesh, L, n0, device).eval_field(state[:n_part].reshape(1, n_part), ext)[2]
+    half_sum = _probe(n_part, N_mesh, L, n0, device).eval_field(state[:n_part].reshape(1, n_part), ext, fields=False)[2]
     return float(half_sum[0])
 
 

@@ -13,6 +13,7 @@ constexpr int SWAVES = SBLOCK / 64;  // kinetic-energy partials are then grouped
 
 struct SolveIO {
   const acc_t* acc;        // [S][env][Ng] deposit (weight sums, 2^-fg units, S sub-rows), or null when rhs is given
+  acc_t* acc_clear;        // = acc, or null: the row is zeroed once it has been read (the probes' own row: no memset per probe)
   const double* rhs;       // [env][Ng] right-hand side taken as it is (pic_solve_poisson)
   const double* ke_part;   // [env][nblk] or null
   double* n;               // [env][Ng] density out, or null
@@ -35,6 +36,8 @@ __device__ __forceinline__ void solve_environment(const SolveIO& io, int env, in
       const double nj = ((double)acc_row_sum(io.acc + row, j, S, sub) * unit) * scale;
       if (io.n) io.n[row + j] = nj;
       sb[j] = nj - n0;
+      if (io.acc_clear)
+        for (int s = 0; s < S; ++s) io.acc_clear[row + (size_t)s * sub + j] = 0;
     }
   } else {
     for (int j = tid; j < Ng; j += SBLOCK) sb[j] = io.rhs[row + j];

@@ -128,6 +128,8 @@ struct pic_handle {
   double* aux_n = nullptr;        // probe outputs
   double* aux_E = nullptr;
   double* aux_pe = nullptr;
+  double* h_probe_pe = nullptr;   // pinned host: the energy of a probe, written by the solve itself (pic_eval_field of a small host state)
+  bool probe_row_clean = false;   // the probes' accumulator row is zero (the solve of the last probe cleared it behind its read)
   double* aux_phi = nullptr;
   int mid_stage = 0;              // pic_step_stage: force evaluations of the current step already done (0 = between steps)
   double* KE = nullptr;
@@ -838,6 +840,7 @@ int pic_create(const pic_config* cfg, pic_handle** out) {
   h->PEr = h->KE + 2 * (size_t)cfg->num_envs;
   CREATE_CHK(hipHostMalloc((void**)&h->h_scal, 3 * sbytes, hipHostMallocDefault));
   if (gbytes <= ((size_t)256 << 10)) CREATE_CHK(hipHostMalloc((void**)&h->h_fields, 3 * gbytes, hipHostMallocDefault));
+  CREATE_CHK(hipHostMalloc((void**)&h->h_probe_pe, sbytes, hipHostMallocDefault));
   CREATE_CHK(hipMalloc((void**)&h->aux_pe, sbytes));
   CREATE_CHK(hipMemsetAsync(h->aux_pe, 0, sbytes, h->stream));
   CREATE_CHK(hipMalloc((void**)&h->bad, sizeof(unsigned long long)));
@@ -862,6 +865,7 @@ int pic_destroy(pic_handle* h) {
   if (h->h_scal) hipHostFree(h->h_scal);
   if (h->h_part) hipHostFree(h->h_part);
   if (h->h_fields) hipHostFree(h->h_fields);
+  if (h->h_probe_pe) hipHostFree(h->h_probe_pe);
   if (h->own_stream) hipStreamDestroy(h->own_stream);
   delete h;
   return PIC_OK;
@@ -1420,20 +1424,27 @@ int pic_get_cic(pic_handle* h, int env, int64_t* indx_l, int64_t* indx_r, double
 }
 
 // deposit of the positions in h->scratch into the probe accumulator, then one solve with `ext` added
-static int probe_solve(pic_handle* h, const double* E_ext, bool want_phi) {
+// Deposit + solve of the positions at `xs` ([env][ld], device-readable: h->scratch, or pinned host memory) into the aux meshes.
+// pe_out: where the solve leaves 0.5 sum(E^2) dx per environment (h->aux_pe, or pinned host memory).
+static int probe_solve(pic_handle* h, const double* E_ext, bool want_phi, void* xs = nullptr, double* pe_out = nullptr) {
   const size_t gbytes = (size_t)h->cfg.num_envs * h->cfg.Ng * sizeof(double);
   const double* ext = nullptr;
   if (E_ext) {
     HIPCHK(h, hipMemcpyAsync(h->probe_ext, E_ext, gbytes, hipMemcpyHostToDevice, h->stream));
     ext = h->probe_ext;
   }
-  HIPCHK(h, hipMemsetAsync(h->probe_acc, 0, row_elems(h) * sizeof(acc_t), h->stream));
-  launch_sweep(h, ST_PROBE, h->scratch, h->scratch, 0, 0, 0, -1, Control{}, h->probe_acc, nullptr);
+  if (!xs) xs = h->scratch;
+  // (the solve zeroes the row behind its read: one command less per probe; a probe that failed half way leaves it unknown)
+  if (!h->probe_row_clean) HIPCHK(h, hipMemsetAsync(h->probe_acc, 0, row_elems(h) * sizeof(acc_t), h->stream));
+  h->probe_row_clean = false;
+  launch_sweep(h, ST_PROBE, xs, xs, 0, 0, 0, -1, Control{}, h->probe_acc, nullptr);
   SolveIO o{};
-  o.acc = h->probe_acc; o.out.ext = ext; o.n = h->aux_n; o.out.E = h->aux_E; o.out.PEr = h->aux_pe;
+  o.acc = h->probe_acc; o.acc_clear = h->probe_acc; o.out.ext = ext; o.n = h->aux_n; o.out.E = h->aux_E;
+  o.out.PEr = pe_out ? pe_out : h->aux_pe;
   if (want_phi) o.out.phi = h->aux_phi;
   launch_solve(h, o);
   HIPCHK(h, hipGetLastError());
+  h->probe_row_clean = true;
   return PIC_OK;
 }
 
@@ -1441,13 +1452,33 @@ int pic_eval_field(pic_handle* h, const void* x, int mem_kind, const double* E_e
                    double* half_sum_E2_dx) {
   if (!h || !x) return fail(h, PIC_EINVAL, "pic_eval_field: null argument");
   HIPCHK(h, hipSetDevice(h->cfg.device_id));
+  const size_t gbytes = (size_t)h->cfg.num_envs * h->cfg.Ng * sizeof(double);
+  const size_t E = (size_t)h->cfg.num_envs, row = (size_t)h->cfg.N * h->esz;
+  // A small host state (Reward.compute_reward of a trainer that only changed its imports: reward.py:48-50, once per step): the
+  // positions go into the pinned staging buffer with a host copy and the probe sweep reads them from there, the solve writes
+  // the energy into pinned memory -- two kernels and one wait instead of seven commands (78 -> 3x us per call at N = 5000).
+  if (mem_kind == PIC_HOST && h->fmt != FMT_U32 && E * row <= kTinyState / 2 && ensure_part_staging(h)) {
+    const size_t pitch = (size_t)h->ld * h->esz;
+    HIPCHK(h, hipStreamSynchronize(h->stream));          // (the staging buffer may still be the target of an earlier read-back)
+    for (size_t e = 0; e < E; ++e) {
+      char* dst = static_cast<char*>(h->h_part) + e * pitch;
+      std::memcpy(dst, static_cast<const char*>(x) + e * row, row);
+      std::memset(dst + row, 0, pitch - row);
+    }
+    int rc = probe_solve(h, E_ext, false, h->h_part, h->h_probe_pe);
+    if (rc) return rc;
+    if (n) HIPCHK(h, hipMemcpyAsync(n, h->aux_n, gbytes, hipMemcpyDeviceToHost, h->stream));
+    if (E_mesh) HIPCHK(h, hipMemcpyAsync(E_mesh, h->aux_E, gbytes, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (half_sum_E2_dx) std::memcpy(half_sum_E2_dx, h->h_probe_pe, E * sizeof(double));
+    return PIC_OK;
+  }
   int rc = ensure_scratch(h);
   if (rc) return rc;
   rc = upload_positions(h, h->scratch, x, mem_kind);
   if (rc) return rc;
   rc = probe_solve(h, E_ext, false);
   if (rc) return rc;
-  const size_t gbytes = (size_t)h->cfg.num_envs * h->cfg.Ng * sizeof(double);
   if (n) HIPCHK(h, hipMemcpyAsync(n, h->aux_n, gbytes, hipMemcpyDeviceToHost, h->stream));
   if (E_mesh) HIPCHK(h, hipMemcpyAsync(E_mesh, h->aux_E, gbytes, hipMemcpyDeviceToHost, h->stream));
   if (half_sum_E2_dx)

@@ -14,6 +14,7 @@ act = E_field(L, Ng, M)
 sim.set_actuator(act)
 rng = np.random.default_rng(0)
 actions = rng.uniform(-1.25, 1.25, (4096, 2 * M))
+state0 = sim.get_state()
 
 
 def timed(label, body, n=3000, warm=500):
@@ -46,6 +47,21 @@ def host_feedback(k):            # run_feedback.py:130-168 on the host: E_mesh r
 
 
 timed("host feedback loop: E_mesh read back + FFT + E_field.compute_E + update_state(E_ext)", host_feedback)
+
+from ocplasma_amd import Reward  # noqa: E402
+rew = Reward(sim.get_state(), N_mesh=Ng, L=L, n_actions=2 * M)
+
+
+def trainer_iteration(k):        # ddpg.py:421-468 with only the import lines changed: the reward deposits the state once more
+    a = actions[k % 4096]
+    act.update_E(a[:M], a[M:])
+    sim.update_state(act.compute_E())
+    nxt = sim.get_state()
+    return rew.compute_reward(nxt, a)
+
+
+timed("trainer iteration as the reference writes it: update_state(E) + get_state + Reward.compute_reward", trainer_iteration, n=1500, warm=200)
+timed("  ... Reward.compute_reward(state, action) alone (a deposit + solve of a host state)", lambda k: rew.compute_reward(state0, actions[k % 4096]), n=1500, warm=200)
 h = sim._ensure_handle()
 timed("raw handle: pic_step(NULL, 1) through ctypes", lambda k: h.step(None, 1))
 timed("raw handle: 10 steps per call", lambda k: h.step(None, 10), n=500, warm=50)
