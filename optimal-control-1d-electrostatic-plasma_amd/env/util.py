@@ -90,7 +90,7 @@ def compute_electric_energy(x: np.ndarray, dx: float, N: int, N_mesh: int, n0: f
                             device: int = 0):
     """util.py:119-131: 0.5 * sum(E_mesh^2) * dx * N / L, reduced on the device."""
     x[:N] = np.mod(x[:N], L)
-    half_sum = probe_handle(N, N_mesh, L, n0, interpol, device).eval_field(_positions(x, N), None)[2]
+    half_sum = probe_handle(N, N_mesh, L, n0, interpol, device).eval_field(_positions(x, N), None, fields=False)[2]
     return float(half_sum[0]) * (N / L)
 
 
