@@ -556,7 +556,11 @@ const char* pic_last_error(pic_handle* h) { return h ? h->err.c_str() : g_create
 // pic_get_particles wants them adjacent).
 hipError_t alloc_particles(pic_handle* h, size_t pbytes) {
   constexpr size_t kMinBytes = (size_t)256 << 20;
-  constexpr size_t kStride = (size_t)3 << 30;       // memory laid down between two timed candidates (a region is 32 GiB)
+  // Memory laid down between two timed candidates (a region is 32 GiB).  Everything the search allocates has to be given back, and
+  // the driver wipes released memory before it hands it out again (~30 ms per GB, asynchronously): whatever allocates next on the
+  // device waits for that.  An untouched 32 GiB spacer (or 11 GiB strides) that carried the search out of x's own region at once
+  // found the fast pair on every fresh box, and made the next pic_create of a create / destroy loop take 0.4-3 s: not worth it.
+  constexpr size_t kStride = (size_t)3 << 30;
   constexpr double kGain = 1.10;                    // best / slowest rate at which the search has found what it looks for
   constexpr int kPatience = 14;                     // timed pairs without improvement before giving up: 14 strides = 42 GiB, more than the
                                                     // 32 GiB a region spans (6 gave up inside x's own region on some boxes: 1049 instead of 958 us)
@@ -599,6 +603,9 @@ hipError_t alloc_particles(pic_handle* h, size_t pbytes) {
   size_t since_timed = kStride;                                       // the first block is timed
   if (ok) ok = hipMemsetAsync(h->x, 0, pbytes, h->stream) == hipSuccess;
   while (ok && (int)blocks.size() < kMaxBlocks && (blocks.size() + 2) * pbytes <= budget) {
+    // (the clock is read before every allocation too: right after the process has released gigabytes -- a create / destroy loop --
+    // hipMalloc itself can take milliseconds per block until the release has gone through)
+    if (seconds() > kMaxSeconds) break;
     void* b = nullptr;
     if (hipMalloc(&b, pbytes) != hipSuccess) break;
     blocks.push_back(b);
@@ -606,7 +613,10 @@ hipError_t alloc_particles(pic_handle* h, size_t pbytes) {
     if (since_timed < kStride && blocks.size() > 3) continue;         // (the first blocks are all timed: recycled memory often pairs at once)
     since_timed = 0;
     float ms = 0.f;
-    ok = pair_ms(b, &ms);
+    // (the first pair is timed twice and the first reading dropped: after an idle spell the clocks are still ramping, the
+    // reading comes out 5-10 % slow, and as "the slowest seen" it made the next pair of the SAME kind look like a find)
+    if (timed == 0) ok = pair_ms(b, &ms);
+    if (ok) ok = pair_ms(b, &ms);
     if (!ok) break;
     ++timed;
     if (!best || ms < best_ms) { best = b; best_ms = ms; since_better = 0; } else ++since_better;
