@@ -134,18 +134,6 @@ __global__ __launch_bounds__(BLOCK) void record_particles_kernel(const typename 
   }
 }
 
-// energies of the step just finished -> slot `s` of a history [steps][3][num_envs] (KE, PE, PE_reward)
-__global__ __launch_bounds__(BLOCK) void record_energies_kernel(const double* __restrict__ KE, const double* __restrict__ PE,
-                                                                const double* __restrict__ PEr, double* __restrict__ hist,
-                                                                int s, int nenv) {
-  const int e = blockIdx.x * BLOCK + threadIdx.x;
-  if (e >= nenv) return;
-  double* slot = hist + (size_t)s * 3 * nenv;
-  slot[e] = KE[e];
-  slot[nenv + e] = PE[e];
-  slot[2 * nenv + e] = PEr[e];
-}
-
 // Twiddle table of the Fourier modes: tw[m-1][j] = cos(2 pi m j / Ng), tw[rows + m-1][j] = sin(2 pi m j / Ng), m = 1..rows.
 // The angle is reduced exactly in integers before the trig call.
 __global__ __launch_bounds__(BLOCK) void twiddle_kernel(double* __restrict__ tw, int Ng, int rows) {
