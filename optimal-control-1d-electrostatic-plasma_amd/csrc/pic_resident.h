@@ -42,6 +42,11 @@ struct ResidentEdge {      // entry and exit of a launch
   // particles before the first field phase.
   const unsigned long long* q1_in;    // [env][R (Ng + 2)] left by the previous launch, or null: deposit from the particles
   unsigned long long* q1_out;         // [env][R (Ng + 2)]
+  // ... and, for a handful of environments, so do the cell and weights every particle's q1 was located with (kernels that carry
+  // them, up to 10 particles per lane): [env] blocks of 64 NW PPT cells (int) followed by 2 (TSC: 3) arrays of as many weights.
+  // Without them the first particle phase behind a mesh taken over locates every q1 again (1.8 us of a 22 us launch at N = 5000).
+  const void* carry_in;               // valid together with q1_in, or null
+  void* carry_out;                    // or null
   unsigned long long* bad;
   void* snap;              // [nsteps][2][env][N] positions (as floats of the particle dtype) and velocities after every step, or null
 };
@@ -232,6 +237,11 @@ __global__ __launch_bounds__(NW * 64) void resident_kernel(typename P::X* __rest
   const bool has_ext = mode & RM_EXT;
   const unsigned long long* q1_in = io.e.q1_in;      // (by value here: used at entry only)
   const bool took_over = q1_in != nullptr;           // the q1 mesh comes from the previous launch
+  constexpr int NWT = SHAPE == PIC_TSC ? 3 : 2;
+  constexpr bool kHandCarry = kCarry && PPT <= 10 && sizeof(T) == 8;   // (16 particles per lane leave no registers for it, and the
+                                                                        // float32 kernels spill with it: they locate q1 again)
+  constexpr size_t kCarryBlock = (size_t)NT * PPT * (sizeof(int) + (NWT == 2 ? 2 : 4) * sizeof(T));   // bytes per environment: cell + weights (TSC: padded to 4)
+  const char* carry_in = kHandCarry && took_over ? static_cast<const char*>(io.e.carry_in) : nullptr;
 
   // The q1 mesh of the previous launch is requested first and the particles after it: the first field phase needs the mesh
   // only, so that the particles' latency runs under it.
@@ -276,8 +286,8 @@ __global__ __launch_bounds__(NW * 64) void resident_kernel(typename P::X* __rest
   // step); without it the gather locates again and the kernel needs ~50 registers fewer, so that two workgroups
   // share a CU -- the better trade once there are more environments than CUs (host: launch_resident).
   constexpr int NCAR = kCarry ? PPT : 1;
-  int js[NCAR];
-  T wgt[NCAR][SHAPE == PIC_TSC ? 3 : 2];
+  int js[NCAR] = {};
+  T wgt[NCAR][SHAPE == PIC_TSC ? 3 : 2] = {};
 
   // the external field of a call that holds it for all its steps: one copy in LDS, made here
   if (has_ext && !(mode & (RM_PER_STEP | RM_FEEDBACK))) {
@@ -321,6 +331,22 @@ __global__ __launch_bounds__(NW * 64) void resident_kernel(typename P::X* __rest
   }
   __syncthreads();
   PIC_STAMP(3);
+  if (kHandCarry && carry_in) {
+    // Requested HERE, behind the entry's barrier: the first field phase (no memory traffic of its own) runs over their latency,
+    // and the wait for the q1 mesh above does not have to count them (requested with the particles they held the entry up by
+    // 1.2 us: the compiler drains every load in flight there).  Every slot: the buffer holds 64 NW PPT entries whatever N is.
+    const int* cj = reinterpret_cast<const int*>(carry_in + (size_t)env * kCarryBlock);
+    typedef T TW __attribute__((ext_vector_type(NWT == 2 ? 2 : 4)));
+    const TW* cw = reinterpret_cast<const TW*>(cj + NT * PPT);
+#pragma unroll
+    for (int s = 0; s < PPT; ++s) {
+      const int e = s * NT + tid;
+      js[kCarry ? s : 0] = cj[e];
+      const TW w = cw[e];
+      wgt[kCarry ? s : 0][0] = w.x; wgt[kCarry ? s : 0][1] = w.y;
+      if (SHAPE == PIC_TSC) wgt[kCarry ? s : 0][SHAPE == PIC_TSC ? 2 : 0] = w[2];
+    }
+  }
 
   double ke = 0.0;               // sum of p^2 of this lane's particles after the step just made
   for (int step = 0; step < nsteps; ++step) {
@@ -371,7 +397,7 @@ __global__ __launch_bounds__(NW * 64) void resident_kernel(typename P::X* __rest
       // and the locate goes into the phase's own loop there: tests/test_host_cpu.py holds every launchable kernel to zero scratch.)
       constexpr bool kRelocateInLoop = kCarry && sizeof(T) == 4 && (SHAPE == PIC_TSC || (PPT == 16 && !P::kFixed));
       const bool relocate = kRelocateInLoop && took_over && step == 0 && st == ST_B;
-      if (kCarry && !kRelocateInLoop && took_over && step == 0 && st == ST_B) {
+      if (kCarry && !kRelocateInLoop && took_over && !carry_in && step == 0 && st == ST_B) {
 #pragma unroll
         for (int s = 0; s < PPT; ++s) {
           js[kCarry ? s : 0] = 0;
@@ -473,6 +499,20 @@ __global__ __launch_bounds__(NW * 64) void resident_kernel(typename P::X* __rest
   }
   if (edge.q1_out)
     for (int i = tid; i < words; i += NT) edge.q1_out[(size_t)env * words + i] = accA_w[i];
+  if (kHandCarry && edge.carry_out && nsteps > 0) {  // (js / wgt: sub-stage D's last locate = the next step's q1; every slot)
+    int* cj = reinterpret_cast<int*>(static_cast<char*>(edge.carry_out) + (size_t)env * kCarryBlock);
+    typedef T TW __attribute__((ext_vector_type(NWT == 2 ? 2 : 4)));
+    TW* cw = reinterpret_cast<TW*>(cj + NT * PPT);
+#pragma unroll
+    for (int s = 0; s < PPT; ++s) {
+      const int e = s * NT + tid;
+      cj[e] = js[kCarry ? s : 0];
+      TW w = {};
+      w.x = wgt[kCarry ? s : 0][0]; w.y = wgt[kCarry ? s : 0][1];
+      if (SHAPE == PIC_TSC) w[2] = wgt[kCarry ? s : 0][SHAPE == PIC_TSC ? 2 : 0];
+      cw[e] = w;
+    }
+  }
   if (bad) atomicAdd(edge.bad, (unsigned long long)bad);
   PIC_STAMP(25);
 

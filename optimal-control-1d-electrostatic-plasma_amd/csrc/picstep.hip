@@ -123,6 +123,8 @@ struct pic_handle {
   size_t traj_bytes = 0;
   unsigned long long* res_q1 = nullptr;   // resident schedule: [env][R (Ng + 2)] LDS mesh of the next step's q1 deposit, launch to launch
   bool res_q1_valid = false;
+  void* res_carry = nullptr;              // ... and the cell and weights of every particle's q1 (pic_resident.h: ResidentEdge), or null
+  bool res_carry_valid = false;
   const InlineDoubles* inline_act = nullptr;   // streaming schedule, for the duration of a call: the held action rides in the sweeps' argument blocks
   Feedback fb{};                  // feedback outputs wanted from the NEXT post-step solve of the streaming schedule (fb.M = 0: none)
   double* aux_n = nullptr;        // probe outputs
@@ -389,6 +391,9 @@ void launch_resident(pic_handle* h, const StepControl& sc, int nsteps, double* h
   // the LDS mesh with the next step's q1 deposit travels from launch to launch (pic_invalidate and every reload drop it)
   io.e.q1_in = h->res_q1_valid ? h->res_q1 : nullptr;
   io.e.q1_out = h->res_q1;
+  io.e.carry_in = h->res_q1_valid && h->res_carry_valid ? h->res_carry : nullptr;
+  io.e.carry_out = h->res_carry;
+  h->res_carry_valid = h->res_carry != nullptr && nsteps > 0;
   h->res_q1_valid = true;
   io.mode = (sc.inline_n > 0 ? RM_ACT_INLINE : 0) | (sc.ctl.ext || sc.ctl.act || sc.fb.M > 0 ? RM_EXT : 0) | (sc.ext_step || sc.act_step ? RM_PER_STEP : 0) |
             (sc.fb.M > 0 ? RM_FEEDBACK : 0) | (snap ? RM_SNAP : 0) | (hist || sc.fb.M > 0 ? RM_RECORD : 0);
@@ -833,6 +838,13 @@ int pic_create(const pic_config* cfg, pic_handle** out) {
     const size_t qbytes = (size_t)cfg->num_envs * h->res_R * stride * sizeof(unsigned long long);
     CREATE_CHK(hipMalloc((void**)&h->res_q1, qbytes));
     CREATE_CHK(hipMemsetAsync(h->res_q1, 0, qbytes, h->stream));
+    // cells and weights of the q1 positions travel with it where a launch is latency, not traffic: a handful of environments
+    // (20 bytes per particle each way: 256 environments would spend 8 us on them), kernels that carry them (pic_resident.h: kHandCarry)
+    if (!h->res_lean && h->res_ppt <= 10 && h->esz == 8 && cfg->num_envs <= 32) {
+      const size_t cbytes = (size_t)cfg->num_envs * h->res_nw * 64 * h->res_ppt * (sizeof(int) + (cfg->interpol == PIC_TSC ? 4 : 2) * h->esz);
+      CREATE_CHK(hipMalloc(&h->res_carry, cbytes));
+      CREATE_CHK(hipMemsetAsync(h->res_carry, 0, cbytes, h->stream));
+    }
   }
   CREATE_CHK(hipMalloc((void**)&h->ke_part, (size_t)cfg->num_envs * h->nblk * sizeof(double)));
   CREATE_CHK(hipMemsetAsync(h->ke_part, 0, (size_t)cfg->num_envs * h->nblk * sizeof(double), h->stream));
@@ -868,7 +880,7 @@ int pic_destroy(pic_handle* h) {
   prof_drain(h);
   for (hipEvent_t e : h->ev) hipEventDestroy(e);
   void* bufs[] = {h->x, h->scratch, h->stage, h->ring, h->ke_part, h->n, h->E_mesh, h->phi, h->ext, h->ext2, h->probe_ext,
-                  h->basis, h->act, h->modes, h->aux_n, h->aux_E, h->aux_pe, h->aux_phi, h->KE, h->bad, h->tw, h->traj, h->res_q1};
+                  h->basis, h->act, h->modes, h->aux_n, h->aux_E, h->aux_pe, h->aux_phi, h->KE, h->bad, h->tw, h->traj, h->res_q1, h->res_carry};
   for (void* b : bufs)
     if (b) hipFree(b);
   if (h->v_separate && h->v) hipFree(h->v);
