@@ -122,7 +122,8 @@ def test_one_call_rollouts_equal_the_step_by_step_loops(oc, po, N, Ng, bpe, dtyp
 
 def test_resident_calls_hand_the_next_deposit_over(oc, po):
     """Single-step calls of the resident schedule take the LDS mesh of the next step's first deposit over from the call before
-    (no entry deposit, particles loaded under the first field phase): same bits as one multi-step call and as the streaming
+    (no entry deposit, particles loaded under the first field phase) -- and, in float64 handles of at most 32 environments like
+    this one, the cell and weights every particle's first position was located with: same bits as one multi-step call and as the streaming
     sweeps, also across everything that must drop the hand-over (invalidate after a write through the views, set_particles,
     a staged step)."""
     import torch
