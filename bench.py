@@ -161,6 +161,7 @@ def main():
                     help="with --actions: one pic_step_actions call per step (a trainer's loop: the action of step s is only known "
                          "after step s-1) instead of ONE pic_step_actions_traj call for all steps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--probe-passes", type=int, default=100, help="passes of the copy-ceiling probe in front of the warm-up")
     ap.add_argument("--cpu-procs", type=int, default=1, help="processes (one env each) for the CPU baseline")
     ap.add_argument("--profile-steps", type=int, default=-1, help="steps of the event-bracketed pass (-1 = --steps)")
     args = ap.parse_args()
@@ -256,7 +257,7 @@ def main():
     # The copy ceiling of this device for the sweeps' access shape (reported next to the 8 TB/s spec).  Taken BEFORE the steps:
     # 100 passes over scratch arrays of the state's size, which also leave the GPU at its working clock instead of the idle one
     # the CPU baseline left it in (the first ~30 steps after an idle GPU run 3-8 % slow).  Every rank does it.
-    copy_gbs = env.stream_probe(100)
+    copy_gbs = env.stream_probe(args.probe_passes)
     run_steps(args.warmup)
     if cdev != "cpu":
         env.sync()
