@@ -5,10 +5,19 @@ BASELINE config 2 -- bump-on-tail, N = 1e6 particles, Ng = 256, 64 environments 
     python bench.py --gpus 1 --steps 20 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N ...          (no WORLD_SIZE in the environment: starts those N ranks itself, as child
+                                           processes made BEFORE this process touches the GPU, and relays their line)
 
 One rank per GPU; environments are sharded (64 per rank, weak scaling), no collective inside the
 step; the only RCCL traffic is the all-gather of per-environment returns after the K steps.
 Rank 0 prints ONE JSON line (contract in DESIGN.md "Measurement").
+
+Order of the regions (profiles/experiments_r4.md 2): a device that has rested for >= 3 ms runs its next ~60 ms of
+sweeps 13 % -> 1 % slow, whatever ran on it before and whichever handle steps (the CPU leg in front of this script's GPU part
+is such a rest).  The default order therefore times the K headline steps LAST, behind the regions this script measures anyway:
+    cold_start (the first K steps of the handle, on the rested device: reported, round 3's headline) -> steady_state (>= 2 s of
+    steps) -> the event-bracketed pass (K steps, per-kernel durations for `roofline`) -> W warm-up steps -> K timed steps = `value`.
+`--order cold` puts W + K first, as rounds 1-3 had it.  `value` is K steps behind W warm-up steps either way.
 """
 import argparse
 import json
@@ -133,6 +142,20 @@ def cpu_baseline(N, Ng, L, dt, budget_s=20.0, procs=1):
             "host": _host_cpu()}
 
 
+def self_launch(n):
+    """Start `n` ranks of this script under torch.distributed.run on this node (127.0.0.1, a free port) and wait for them."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: what RCCL needs on this host driver
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -153,13 +176,24 @@ def main():
                          "step, turned into E_ext by the device actuator (BASELINE config 3); 0 = no control")
     ap.add_argument("--config", type=int, default=0, choices=[0, 1, 2, 3, 4, 5],
                     help="BASELINE.json configuration by number, at its single-GPU share (overrides the workload flags): "
-                         "1 = N=1e4/Ng=128/1 env fp64; 2 = the default; 3 = two-stream N=1e6/Ng=512/128 envs fp32 fixed-point "
-                         "positions, a new random action every step; 4 = N=4e6/Ng=1024/64 envs fp64; 5 = N=1e7/Ng=256/128 envs fp32")
-    ap.add_argument("--steady-steps", type=int, default=200,
-                    help="steps of a second, longer region timed after the headline one and printed as `steady_state` (0 = skip)")
+                         "1 = N=1e4/Ng=128/1 env fp64; 2 = the default; 3 = two-stream N=1e6/Ng=512/128 envs, float32 velocities with "
+                         "32-bit FIXED-POINT positions (not BASELINE's plain \"fp32\": add --positions float for float32 positions), "
+                         "a new random action every step; 4 = N=4e6/Ng=1024/64 envs fp64; 5 = N=1e7/Ng=256/128 envs fp32")
+    ap.add_argument("--steady-steps", type=int, default=-1,
+                    help="steps of a second, longer region printed as `steady_state` (0 = skip; -1 = about 2 s of GPU work, between "
+                         "200 and 20000 steps: 1950 at config 2 -- long enough for an outside sampler such as rocm-smi to see the "
+                         "device at work and for the figure to span the device's power management)")
+    ap.add_argument("--order", default="warm", choices=["warm", "cold"],
+                    help="warm (default): cold_start, steady_state and the event-bracketed pass run BEFORE the W warm-up and K timed "
+                         "steps, so that the timed region sees the device in its working state; cold: W + K first (rounds 1-3), the "
+                         "other regions behind them")
     ap.add_argument("--per-step-calls", action="store_true",
                     help="with --actions: one pic_step_actions call per step (a trainer's loop: the action of step s is only known "
                          "after step s-1) instead of ONE pic_step_actions_traj call for all steps")
+    ap.add_argument("--history", action="store_true",
+                    help="pic_step_history instead of pic_step: the energies of EVERY step are recorded, so the resident schedule "
+                         "makes every step's post-step refresh (SURVEY 8d's definition of a step; a plain pic_step(nsteps) call "
+                         "skips the refreshes nothing can observe, `refresh: last_only`)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--probe-passes", type=int, default=100, help="passes of the copy-ceiling probe in front of the warm-up")
     ap.add_argument("--cpu-procs", type=int, default=1, help="processes (one env each) for the CPU baseline")
@@ -175,11 +209,17 @@ def main():
         if k not in explicit:                                # an explicit flag beside --config wins
             setattr(args, k, val)
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` as the driver runs the 1-GPU leg: start the N ranks ourselves.  Child processes, made while this
+        # process has not touched the GPU (an exec or fork from a GPU-initialised process takes the machine down on this pool);
+        # their rank 0 prints the JSON line on our stdout, and their exit code is ours.
+        raise SystemExit(self_launch(args.gpus))
+    launched = "WORLD_SIZE" in os.environ       # under torch.distributed.run (also with ONE rank: the RCCL path runs then too)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run, or without WORLD_SIZE set")
 
     # CPU baseline first: with --cpu-procs > 1 it starts worker processes, which must happen before this
     # process initialises the GPU (no exec from a GPU-initialised process on this pool).
@@ -200,7 +240,7 @@ def main():
     torch.cuda.set_device(dev_index)
     cdev = f"cuda:{dev_index}" if backend == "nccl" else "cpu"      # where collective buffers live
     dist = None
-    if world > 1:
+    if launched:
         import torch.distributed as dist
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device(f"cuda:{dev_index}"))
@@ -213,6 +253,9 @@ def main():
             dist.init_process_group(backend)
 
     N, Ng, E, L = args.particles, args.mesh, args.envs, 50.0
+    if args.steady_steps < 0:       # ~2 s: the step moves 96 (48) bytes per particle at ~6 TB/s, and takes >= 14 us however small
+        est_ms = max(0.014, N * E * MOVED_BYTES_PER_PARTICLE_STEP[args.dtype] / 6.0e12 * 1e3)
+        args.steady_steps = int(min(20000, max(200, round(2000.0 / est_ms, -1))))
     tdtype = torch.float64 if args.dtype == "float64" else torch.float32
     env = BatchedPIC(E, N, Ng, L=L, dt=0.1, device=dev_index, dtype=args.dtype, accum_dtype=args.accum,
                      blocks_per_env=args.blocks_per_env, position_dtype=args.positions, interpol=args.interpol)
@@ -246,7 +289,11 @@ def main():
     def run_steps(k):
         """k environment steps in one call: pic_step, or (with --actions) pic_step_actions_traj with a new action for every
         step, E_ext built from it inside the field phases; --per-step-calls: k pic_step_actions calls instead."""
-        if acts is None:
+        if k <= 0:
+            return
+        if acts is None and args.history:
+            env.step_history(None, k)
+        elif acts is None:
             env.step(None, nsteps=k)
         elif args.per_step_calls:
             for i in range(k):
@@ -254,10 +301,38 @@ def main():
         else:
             env._h.step_actions_traj_device(acts.data_ptr(), k)
 
-    # The copy ceiling of this device for the sweeps' access shape (reported next to the 8 TB/s spec).  Taken BEFORE the steps:
-    # 100 passes over scratch arrays of the state's size, which also leave the GPU at its working clock instead of the idle one
-    # the CPU baseline left it in (the first ~30 steps after an idle GPU run 3-8 % slow).  Every rank does it.
+    # The copy ceiling of this device for the sweeps' access shape (reported next to the 8 TB/s spec): 100 passes over scratch
+    # arrays of the state's size.  Every rank does it.
     copy_gbs = env.stream_probe(args.probe_passes)
+
+    def timed_region(k):
+        """k steps on this rank's own clock (stream drained before and after) -> ms per step"""
+        env.sync()
+        t = time.perf_counter()
+        run_steps(k)
+        env.sync()
+        return (time.perf_counter() - t) / k * 1e3
+
+    def event_pass():
+        """K steps with every launch bracketed by HIP events on the library's own stream (the brackets cost ~2 % of a step, so
+        they stay out of `value`) -> (per-kernel {name: (ms, launches)}, ms per step of the pass)"""
+        env.profile(True)
+        ms = timed_region(psteps)
+        prof = env.profile_read()
+        env.profile(False)
+        return prof, ms
+
+    psteps = args.steps if args.profile_steps < 0 else args.profile_steps
+    cold = steady = prof = ms_per_step_events = None
+    if args.order == "warm":
+        # The regions this script measures anyway, in front of the headline one (module docstring): every rank runs them, so that
+        # all devices of a multi-GPU run are in the same state when the timed region starts.
+        cold = {"steps": args.steps, "ms_per_step": timed_region(args.steps)}
+        if args.steady_steps > 0:
+            steady = {"steps": args.steady_steps, "ms_per_step": timed_region(args.steady_steps)}
+        if psteps > 0:
+            prof, ms_per_step_events = event_pass()
+
     run_steps(args.warmup)
     if cdev != "cpu":
         env.sync()
@@ -267,6 +342,8 @@ def main():
         w = env.rewards_torch() if cdev != "cpu" else torch.as_tensor(env.rewards(), device=cdev)
         dist.all_gather([torch.empty_like(w) for _ in range(world)], w)
         dist.all_reduce(torch.zeros(1, device=cdev, dtype=torch.float64), op=dist.ReduceOp.MAX)
+        if args.order == "warm" and args.warmup > 0:
+            run_steps(args.warmup)   # the set-up of the collectives let the device rest: the W warm-up steps once more, behind it
     barrier()
     t0 = time.perf_counter()
     run_steps(args.steps)
@@ -294,37 +371,24 @@ def main():
         per_rank_ms = [float(e[0]) for e in every]
         gather_ms = [float(e[1]) for e in every]
 
-    # health: nothing non-finite, energy conserved over the run
+    if args.order == "cold":
+        # rounds 1-3: the longer region and the event pass behind the headline one
+        if rank == 0 and args.steady_steps > 0:
+            steady = {"steps": args.steady_steps, "ms_per_step": timed_region(args.steady_steps)}
+        if rank == 0 and psteps > 0:
+            prof, ms_per_step_events = event_pass()
+    for region in (cold, steady):
+        if region is not None:
+            region["value"] = N * E / (region["ms_per_step"] * 1e-3)       # this rank's particle-steps/s
+
+    # health: nothing non-finite, energy conserved over the whole run (every region above)
     ke, pe, _ = env.energies()
     drift = float(np.max(np.abs((ke + pe) / (ke0 + pe0) - 1)))
     bad = env.bad_count()
 
-    # A second, longer region on this rank's own clock: the first ~30 steps after an idle GPU run a few per cent slow (clock
-    # ramp), so the headline K-step figure of a short run understates what a rollout sees.  Not part of `value`.
-    steady = None
-    if rank == 0 and args.steady_steps > 0:
-        env.sync()
-        t1 = time.perf_counter()
-        run_steps(args.steady_steps)
-        env.sync()
-        steady = {"steps": args.steady_steps, "ms_per_step": (time.perf_counter() - t1) / args.steady_steps * 1e3}
-        steady["value"] = N * E / (steady["ms_per_step"] * 1e-3)
-
-    # Per-kernel durations: K steps again, every launch bracketed by HIP events on the
-    # library's own stream (the brackets cost ~4 % of a step, so they stay out of `value`).
     roof = None
     kernels = {}
-    ms_per_step_events = None
-    psteps = args.steps if args.profile_steps < 0 else args.profile_steps
-    if rank == 0 and psteps > 0:
-        env.profile(True)
-        env.sync()
-        t1 = time.perf_counter()
-        run_steps(psteps)
-        env.sync()
-        ms_per_step_events = (time.perf_counter() - t1) / psteps * 1e3
-        prof = env.profile_read()
-        env.profile(False)
+    if rank == 0 and prof is not None:
         esz = 8 if args.dtype == "float64" else 4
         for k, (ms, cnt) in prof.items():
             kernels[k] = {"avg_ms": ms / cnt, "launches": cnt}
@@ -373,18 +437,26 @@ def main():
                                   + ("(one pic_step_actions call per step)" if args.per_step_calls else "(one pic_step_actions_traj call)")
                                   if args.actions > 0 else "no control (E_ext = None)") + ", Yoshida-4 step = PIC.update_state",
                    "envs_per_gpu": E, "particles_per_env": N, "mesh": Ng, "dt": env.dt, "schedule": env._h.schedule(),
+                   # the post-step refresh (density, E_mesh, phi, energies: pic.py:145-146) of the steps inside one call
+                   "refresh": "every_step" if (env._h.schedule() == "streaming" or args.history or args.per_step_calls
+                                               or max(args.steps, 1) == 1) else "last_only",
                    "sharding": f"{world} x {E} envs, all-gather of returns only"},
-        # whole-step fractions of the 8 TB/s peak: on the bytes the schedule really moves (12 words per particle-step)
-        # and on SURVEY 8d's algorithmic count (14 words; > the first because sweep A's read is not made at all)
+        # whole-step fraction of the 8 TB/s peak on the bytes the schedule really moves (12 words per particle-step).
+        # survey_112B_equivalent prices the same rate with SURVEY 8d's algorithmic 14 words: NOT a bandwidth fraction (2 of the
+        # 14 words -- sweep A's read -- are never moved), only the figure to hold against SURVEY's 7.14e10 = 100 %.
         "hbm_frac_of_step": value / world * MOVED_BYTES_PER_PARTICLE_STEP[args.dtype] / (HBM_PEAK_GBS * 1e9),
-        "algorithmic_frac_of_step": value / world * ALGORITHMIC_BYTES_PER_PARTICLE_STEP[args.dtype] / (HBM_PEAK_GBS * 1e9),
-        "steady_state": steady,
+        "survey_112B_equivalent": value / world * ALGORITHMIC_BYTES_PER_PARTICLE_STEP[args.dtype] / (HBM_PEAK_GBS * 1e9),
+        # the regions around the headline one, in the order they ran (module docstring); each on rank 0's own clock
+        "order": (["cold_start", "steady_state", "event_pass", "warmup", "timed"] if args.order == "warm"
+                  else ["warmup", "timed", "steady_state", "event_pass"]),
+        "cold_start": cold, "steady_state": steady,
         "per_rank_ms_per_step": per_rank_ms, "returns_all_gather_ms": gather_ms,
         "collective_backend": None if dist is None else dist.get_backend(), "gpus_visible": torch.cuda.device_count(),
         "energy_drift": drift, "bad_positions": bad, "mean_return": float(returns.mean().item()),
         # pic_create's search for two different HBM regions for x and v: (x, v) placements timed, bare-stream GB/s of the pair
-        # kept and of the slowest pair seen
-        "placement": dict(zip(("pairs_timed", "kept_GBs", "slowest_GBs", "seconds"), env._h.placement_info())),
+        # kept and of the slowest pair seen, how the search ended (found | patience | timeout | memory | none) and where its
+        # time went
+        "placement": env._h.placement_stats(),
         "roofline": roof, "kernels": kernels,
     }
     if rank == 0:

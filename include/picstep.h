@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define PICSTEP_ABI_VERSION 3
+#define PICSTEP_ABI_VERSION 4
 
 enum { PIC_F64 = 0, PIC_F32 = 1 };           /* particle dtype (velocities; positions too unless fixed point) */
 enum { PIC_POS_FLOAT = 0,                    /* positions stored in the particle dtype                         */
@@ -39,6 +39,11 @@ enum { PIC_CIC = 0, PIC_TSC = 1 };           /* src/env/interpolate.py:4 (CIC), 
 enum { PIC_PLACE_AUTO = 0,                   /* large states: look for x and v in two different regions of HBM (pic_placement_info) */
        PIC_PLACE_OFF = 1 };                   /* no search: x | v in one allocation                                                 */
 enum { PIC_HOST = 0, PIC_DEVICE = 1 };       /* where a caller buffer lives                   */
+enum { PIC_PLACED_NONE = 0,                  /* pic_placement.outcome: no search (small state or PIC_PLACE_OFF)                    */
+       PIC_PLACED_FOUND = 1,                 /* the pair kept streams >= 10 % faster than the slowest pair seen                    */
+       PIC_PLACED_PATIENCE = 2,              /* fourteen timed pairs without an improvement: all alike, the best of them kept      */
+       PIC_PLACED_TIMEOUT = 3,               /* 100 ms spent: the best pair seen so far kept                                       */
+       PIC_PLACED_MEMORY = 4 };              /* a third of the free memory held (or an allocation failed): the best pair seen kept */
 
 enum {
   PIC_OK = 0,
@@ -280,6 +285,22 @@ int pic_schedule(pic_handle* h);
  * -> how many pairs were timed (1 with rates 0 = small state or search off, nothing timed), the read+write rate of the pair kept
  * and of the slowest pair seen, in GB/s, and the wall time the search took; any pointer may be NULL. */
 int pic_placement_info(pic_handle* h, int* candidates, double* kept_gbytes_per_s, double* slowest_gbytes_per_s, double* seconds);
+
+/* The same report with how the search ended and where its time went (ABI 4).  malloc_seconds is the part a device that has just had
+ * gigabytes released on it makes expensive (the driver wipes released memory before handing it out again: hipMalloc of a 512 MB
+ * block takes 20-150 us on a quiet device and milliseconds there); timing_seconds the streaming passes (filler + one untimed + one
+ * timed pass per pair); free_seconds the release of the blocks not kept. */
+typedef struct {
+  int32_t pairs_timed;             /* 0: no search */
+  int32_t blocks;                  /* candidate blocks allocated in all (timed or walked over) */
+  int32_t outcome;                 /* PIC_PLACED_* */
+  int32_t reserved;
+  double kept_gbytes_per_s;        /* read + write rate of the bare stream over (x, v kept) */
+  double slowest_gbytes_per_s;     /* ... over the slowest pair timed */
+  double seconds;                  /* wall time of the search inside pic_create */
+  double malloc_seconds, timing_seconds, free_seconds;
+} pic_placement;
+int pic_placement_stats(pic_handle* h, pic_placement* out);
 
 int pic_sync(pic_handle* h);
 /* Number of particle positions found non-finite or out of range by the last sweeps (0 = healthy). */

@@ -15,7 +15,7 @@ PIC_POS_FLOAT, PIC_POS_FIXED32 = 0, 1
 PIC_ACC_AUTO, PIC_ACC_FIX64, PIC_ACC_PACKED, PIC_ACC_F64 = 0, 1, 2, 3
 PIC_CIC, PIC_TSC = 0, 1
 PIC_HOST, PIC_DEVICE = 0, 1
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 # accum_dtype spellings of the Python layer -> PIC_ACC_*
 ACCUMULATORS = {None: PIC_ACC_AUTO, "auto": PIC_ACC_AUTO, "fix64": PIC_ACC_FIX64, "fixed": PIC_ACC_PACKED,
@@ -80,11 +80,18 @@ SIGNATURES = {
     "pic_own_stream": [_vp],
     "pic_schedule": [_vp],
     "pic_placement_info": [_vp, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)],
+    "pic_placement_stats": [_vp, _vp],
     "pic_sync": [_vp],
     "pic_bad_count": [_vp, _i64p],
     "pic_last_error": [_vp],
     "pic_abi_version": [],
 }
+
+
+class _Placement(C.Structure):
+    _fields_ = [("pairs_timed", C.c_int32), ("blocks", C.c_int32), ("outcome", C.c_int32), ("reserved", C.c_int32),
+                ("kept_gbytes_per_s", C.c_double), ("slowest_gbytes_per_s", C.c_double), ("seconds", C.c_double),
+                ("malloc_seconds", C.c_double), ("timing_seconds", C.c_double), ("free_seconds", C.c_double)]
 
 
 def library_path():
@@ -241,6 +248,16 @@ class Handle:
         n, kept, slow, sec = C.c_int(), C.c_double(), C.c_double(), C.c_double()
         self._chk(self.lib.pic_placement_info(self._h, C.byref(n), C.byref(kept), C.byref(slow), C.byref(sec)))
         return n.value, kept.value, slow.value, sec.value
+
+    def placement_stats(self):
+        """pic_placement_stats as a dict: pairs_timed, blocks, outcome ("none" | "found" | "patience" | "timeout" | "memory"),
+        kept_GBs, slowest_GBs, seconds, malloc_seconds, timing_seconds, free_seconds."""
+        st = _Placement()
+        self._chk(self.lib.pic_placement_stats(self._h, C.byref(st)))
+        return {"pairs_timed": st.pairs_timed, "blocks": st.blocks,
+                "outcome": ("none", "found", "patience", "timeout", "memory")[st.outcome], "kept_GBs": st.kept_gbytes_per_s,
+                "slowest_GBs": st.slowest_gbytes_per_s, "seconds": st.seconds, "malloc_seconds": st.malloc_seconds,
+                "timing_seconds": st.timing_seconds, "free_seconds": st.free_seconds}
 
     def particles(self):
         x = np.empty((self.num_envs, self.N), dtype=self.dtype)

@@ -15,7 +15,7 @@ RESOURCES = os.path.join(HERE, "csrc", "libpicstep.resources.json")   # register
 INCLUDE = os.path.join(ROOT, "include")
 
 # -ffp-contract=off: the sub-stage arithmetic must round like the NumPy reference (no FMA fusion)
-FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17",
+FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17", "-pthread",
          "-Wno-unused-result", "-Wno-unused-value", "-I" + INCLUDE, "-Rpass-analysis=kernel-resource-usage"]
 
 

@@ -38,13 +38,16 @@
 
 #include <algorithm>
 #include <chrono>
+#include <condition_variable>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
+#include <thread>
 #include <type_traits>
 #include <vector>
 
@@ -61,6 +64,7 @@
 // Host side
 // ---------------------------------------------------------------------------------------------
 enum Format : int { FMT_F64 = 0, FMT_F32 = 1, FMT_U32 = 2 };     // PosF64 / PosF32 / PosU32
+typedef pic_placement PlacementStats;
 constexpr int RING = 8;                                          // accumulator rows in rotation
 
 struct pic_handle {
@@ -90,9 +94,7 @@ struct pic_handle {
   int post_slot = -1;                 // ring row whose post-step solve rides with the next sweep B (inside pic_step only)
   double* hist_row = nullptr;         // where the NEXT post-step solve also records its three energies (step_recording), or null
   double* post_hist_row = nullptr;    // the same for the solve that post_slot stands for
-  int place_tried = 1;                // (x, v) placements pic_create timed (alloc_particles)
-  double place_gbs[2] = {0.0, 0.0};   // streaming rate of the one kept and of the slowest one, GB/s
-  double place_seconds = 0.0;         // wall time the placement search took inside pic_create
+  PlacementStats place{};             // what alloc_particles' search for an (x, v) placement did (pic_placement_stats)
   void* x = nullptr;
   void* v = nullptr;
   void* scratch = nullptr;        // [env][ld] positions of a probe (eval_field / compute_E)
@@ -100,6 +102,7 @@ struct pic_handle {
   // accumulator ring: rows [env][Ng] of 64-bit fixed-point weight sums
   acc_t* ring = nullptr;
   std::vector<int> clean, dirty;  // rows that are zero / rows whose readers have all been enqueued
+  hipError_t ring_error = hipSuccess;   // a clearing memset of ring_take_clean that failed (reported by launch_status)
   int q_slot = -1;                // row holding the deposit of the NEXT step's q1 (sweep A is skipped while >= 0)
   int stage_slot = -1;            // pic_step_stage: row the next stage's field comes from
   int sweep_parity = 0;           // direction of the next push sweep
@@ -191,12 +194,23 @@ int ring_take_clean(pic_handle* h) {
   if (h->clean.empty()) {          // not reached by the step schedule (every sweep clears two retired rows)
     const int s = h->dirty.front();
     h->dirty.erase(h->dirty.begin());
-    hipMemsetAsync(ring_row(h, s), 0, row_elems(h) * sizeof(acc_t), h->stream);
+    // (a failure here must not pass silently as a dirty row: it is kept for the caller's next check, pic_* entry points end
+    // with HIPCHK(h, ring_status(h)) through hipGetLastError's siblings below)
+    const hipError_t e = hipMemsetAsync(ring_row(h, s), 0, row_elems(h) * sizeof(acc_t), h->stream);
+    if (e != hipSuccess && h->ring_error == hipSuccess) h->ring_error = e;
     return s;
   }
   const int s = h->clean.back();
   h->clean.pop_back();
   return s;
+}
+
+// what the launches enqueued since the last check have left behind: the runtime's sticky error, or a failed row clearing
+hipError_t launch_status(pic_handle* h) {
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) { e = h->ring_error; }
+  h->ring_error = hipSuccess;
+  return e;
 }
 
 // the last kernel reading `slot` has been enqueued: any later sweep may clear it
@@ -393,8 +407,6 @@ void launch_resident(pic_handle* h, const StepControl& sc, int nsteps, double* h
   io.e.q1_out = h->res_q1;
   io.e.carry_in = h->res_q1_valid && h->res_carry_valid ? h->res_carry : nullptr;
   io.e.carry_out = h->res_carry;
-  h->res_carry_valid = h->res_carry != nullptr && nsteps > 0;
-  h->res_q1_valid = true;
   io.mode = (sc.inline_n > 0 ? RM_ACT_INLINE : 0) | (sc.ctl.ext || sc.ctl.act || sc.fb.M > 0 ? RM_EXT : 0) | (sc.ext_step || sc.act_step ? RM_PER_STEP : 0) |
             (sc.fb.M > 0 ? RM_FEEDBACK : 0) | (snap ? RM_SNAP : 0) | (hist || sc.fb.M > 0 ? RM_RECORD : 0);
   prof_begin(h, 6);
@@ -439,7 +451,7 @@ int refresh_fields(pic_handle* h) {
   const int f = ring_take_clean(h), qn = ring_take_clean(h);
   launch_sweep(h, ST_REFRESH, h->x, h->v, 0, 0, 0, -1, Control{}, ring_row(h, f), ring_row(h, qn));
   launch_final_solve(h, f);
-  HIPCHK(h, hipGetLastError());
+  HIPCHK(h, launch_status(h));
   h->q_slot = qn;   // ST_REFRESH also deposited the next step's q1
   return PIC_OK;
 }
@@ -546,38 +558,61 @@ int pic_abi_version(void) { return PICSTEP_ABI_VERSION; }
 
 const char* pic_last_error(pic_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
 
-// Where x and v land in HBM decides how fast they stream together.  MI355X's 288 GiB are nine regions of 32 GiB; a kernel
-// that streams two arrays lying in the SAME region runs at 5.25 TB/s, with the arrays in two DIFFERENT regions at
-// 6.05 TB/s, whichever regions and whatever the access pattern (profiles/window_probe.hip: one 120 GiB block, x fixed,
-// v moved through it; profiles/experiments_r2.md 15).  A fresh device hands out neighbouring memory, so x and v of a
-// default allocation share a region almost always.
+// Where x and v land in HBM decides how fast they stream together.  On an unfragmented MI355X the 288 GiB behave as nine regions
+// of 32 GiB: a kernel that streams two arrays lying in the SAME region runs at 5.25 TB/s, with the arrays in two DIFFERENT
+// regions at 6.05 TB/s, whichever regions and whatever the access pattern (profiles/window_probe.hip: one 120 GiB block, x fixed,
+// v moved through it; profiles/experiments_r2.md 15).  A fresh device hands out neighbouring memory, so x and v of a default
+// allocation share a region almost always; on a device whose memory has been through other processes a block is a mixture of
+// pages from several regions (profiles/touch_probe.hip, experiments_r4.md 1: the class of a 64 MB window follows the window of x
+// it is paired with, not the candidate), which is why the search times WHOLE blocks, never windows of them.
 // For particle states that live in HBM (>= 256 MB) x and v are therefore two allocations: x first, then blocks of the same
-// size one after the other (they are laid down in sequence); every few blocks the pair (x, block) is timed with a streaming
-// pass.  The search is a policy on RATIOS, not on this part's numbers: it ends when the best pair seen streams >= 10 % faster
-// than the slowest one seen (the two kinds have been told apart and we hold a fast one), after fourteen timed pairs without an
-// improvement (42 GiB walked, all pairs alike: nothing to gain on this device), after 100 ms, or when a third of the free memory is
-// held; everything but x and v is freed before pic_create returns.  pic_config.placement = PIC_PLACE_OFF skips it (x | v in
-// one block).  Smaller states keep x | v in one block too (they sit in the Infinity Cache, and the one-copy read-back of
-// pic_get_particles wants them adjacent).
+// size one after the other (they are laid down in sequence), and the pair (x, newest block) is timed with a streaming pass again
+// and again while the blocks keep coming.  The search is a policy on RATIOS, not on this part's numbers: it ends when the best
+// pair seen streams >= 10 % faster than the slowest one seen (the two kinds have been told apart and we hold a fast one), after
+// 42 GiB walked without an improvement (more than a region, all pairs alike: nothing to gain on this device), after 100 ms, or
+// when a third of the free memory is held; everything but x and v is freed before pic_create returns.
+// pic_config.placement = PIC_PLACE_OFF skips it (x | v in one block).  Smaller states keep x | v in one block too (they sit in
+// the Infinity Cache, and the one-copy read-back of pic_get_particles wants them adjacent).
+//
+// Where the time goes (round 4, profiles/experiments_r4.md 1).  Nothing is paid for the first touch of a block (touch_probe: first
+// pass 330 us, later ones 347), so a candidate is not cleared here and a reading is ONE pass behind one untimed pass.  What costs
+// is hipMalloc on a device nobody has used yet: the driver clears memory it hands out for the first time, 1.3 ms per 512 MB block
+// (released memory is cleared in the background and comes back in 20-70 us), and a first create on a fresh box has x at the very
+// start of a region -- 31 GiB = 80 ms of allocations away from the first block that pairs well with it.  So the blocks are
+// allocated by a thread of their own, at most kLead ahead of the one being timed, while this thread does nothing but time: the
+// walk advances at the allocator's speed, the stream never rests (a device that has rested >= 3 ms runs its next 10-20 ms 4-13 %
+// slow -- early_steps3.py -- and a search whose readings straddle that ramp sees a "10 % faster" pair of the SAME kind; ~10 ms of
+// filler passes over x absorb the ramp of the rested device a create starts on).
+struct BlockFeed {                                  // candidate blocks, allocated by a thread of their own (alloc_particles)
+  std::mutex m;
+  std::condition_variable cv;
+  std::vector<void*> blocks;                        // in allocation order; only ever grown by the feeder
+  size_t taken = 0;                                 // blocks.size() when the timing thread last took one
+  bool stop = false, done = false;
+  double malloc_seconds = 0.0;
+};
+
 hipError_t alloc_particles(pic_handle* h, size_t pbytes) {
   constexpr size_t kMinBytes = (size_t)256 << 20;
-  // Memory laid down between two timed candidates (a region is 32 GiB).  Everything the search allocates has to be given back, and
-  // the driver wipes released memory before it hands it out again (~30 ms per GB, asynchronously): whatever allocates next on the
-  // device waits for that.  An untouched 32 GiB spacer (or 11 GiB strides) that carried the search out of x's own region at once
-  // found the fast pair on every fresh box, and made the next pic_create of a create / destroy loop take 0.4-3 s: not worth it.
-  constexpr size_t kStride = (size_t)3 << 30;
+  // Everything the search allocates has to be given back, and the driver wipes released memory before it hands it out again
+  // (asynchronously; whatever allocates next on the device may wait for that): an untouched 32 GiB spacer that carried the search out
+  // of x's own region at once made the next pic_create of a create / destroy loop take 0.4-3 s (experiments_r3.md 18).  Blocks of
+  // the state's own size, given back within the call, do not.
+  constexpr size_t kLead = (size_t)3 << 30;         // the feeder stays at most this far ahead of the block being timed
   constexpr double kGain = 1.10;                    // best / slowest rate at which the search has found what it looks for
-  constexpr int kPatience = 14;                     // timed pairs without improvement before giving up: 14 strides = 42 GiB, more than the
-                                                    // 32 GiB a region spans (6 gave up inside x's own region on some boxes: 1049 instead of 958 us)
+  constexpr size_t kPatience = (size_t)42 << 30;    // walked without an improvement before giving up: more than the 32 GiB a region
+                                                    // spans (15 GiB gave up inside x's own region on some boxes: 1049 instead of 958 us)
   constexpr double kMaxSeconds = 0.100;
   constexpr int kMaxBlocks = 192;
+  PlacementStats& st = h->place;
+  st = PlacementStats{};
   if (2 * pbytes < kMinBytes || h->cfg.placement == PIC_PLACE_OFF) {
     const hipError_t e = hipMalloc(&h->x, 2 * pbytes);
     h->v = static_cast<char*>(h->x) + pbytes;
     return e;
   }
   const auto t_begin = std::chrono::steady_clock::now();
-  auto seconds = [&]() { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count(); };
+  auto seconds = [t_begin]() { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count(); };
   hipError_t e = hipMalloc(&h->x, pbytes);
   if (e != hipSuccess) return e;
   h->v_separate = true;
@@ -589,49 +624,99 @@ hipError_t alloc_particles(pic_handle* h, size_t pbytes) {
   long long nb = n2 / ((long long)BLOCK * 8);
   if (nb < 256) nb = 256;
   const long long chunk2 = (n2 + nb - 1) / nb;
-  auto pair_ms = [&](void* vb, float* ms) {                            // one warm pass, two timed ones over x and the candidate
-    double2* a = static_cast<double2*>(h->x);
-    double2* b = static_cast<double2*>(vb);
-    bool good = hipMemsetAsync(vb, 0, pbytes, h->stream) == hipSuccess;
-    hipLaunchKernelGGL(stream_probe_kernel, dim3((unsigned)nb), dim3(BLOCK), 0, h->stream, a, b, n2, chunk2, 1.0, 0);
-    good = good && hipGetLastError() == hipSuccess && hipEventRecord(e0, h->stream) == hipSuccess;
-    for (int r = 0; r < 2; ++r)
-      hipLaunchKernelGGL(stream_probe_kernel, dim3((unsigned)nb), dim3(BLOCK), 0, h->stream, a, b, n2, chunk2, 1.0, 0);
-    return good && hipGetLastError() == hipSuccess && hipEventRecord(e1, h->stream) == hipSuccess &&
-           hipEventSynchronize(e1) == hipSuccess && hipEventElapsedTime(ms, e0, e1) == hipSuccess;
+  const long long nbh = (nb + 1) / 2, chunk2h = (n2 / 2 + nbh - 1) / nbh;
+  double2* xa = static_cast<double2*>(h->x);
+  // filler: the two halves of x streamed against each other (the same kernel at half the size), ~0.1 ms per GB of state
+  auto filler = [&](int passes) {
+    for (int r = 0; r < passes; ++r)
+      hipLaunchKernelGGL(stream_probe_kernel, dim3((unsigned)nbh), dim3(BLOCK), 0, h->stream, xa, xa + n2 / 2, n2 / 2, chunk2h, 1.0, r & 1);
   };
-  const double gb_per_ms = 2.0 * 4.0 * (double)pbytes / 1e6;          // 2 passes, 2 arrays read and written: GB/s = this / ms
-  std::vector<void*> blocks;                                          // every block taken after x, in order
+  const double pass_ms_guess = 2.0 * (double)pbytes / 5.0e9;           // one filler pass moves 2 x pbytes at ~5 TB/s
+  const int fill_1ms = std::max(1, (int)std::ceil(1.0 / pass_ms_guess));
+  auto pair_ms = [&](void* vb, float* ms) {                            // one untimed pass over (x, candidate), one timed
+    double2* b = static_cast<double2*>(vb);
+    const double t0 = seconds();
+    hipLaunchKernelGGL(stream_probe_kernel, dim3((unsigned)nb), dim3(BLOCK), 0, h->stream, xa, b, n2, chunk2, 1.0, 0);
+    bool good = hipGetLastError() == hipSuccess && hipEventRecord(e0, h->stream) == hipSuccess;
+    hipLaunchKernelGGL(stream_probe_kernel, dim3((unsigned)nb), dim3(BLOCK), 0, h->stream, xa, b, n2, chunk2, 1.0, 0);
+    good = good && hipGetLastError() == hipSuccess && hipEventRecord(e1, h->stream) == hipSuccess &&
+           hipEventSynchronize(e1) == hipSuccess && hipEventElapsedTime(ms, e0, e1) == hipSuccess;
+    st.timing_seconds += seconds() - t0;
+    return good;
+  };
+  const double gb_per_ms = 4.0 * (double)pbytes / 1e6;                // one pass, 2 arrays read and written: GB/s = this / ms
+
+  BlockFeed feed;
+  const size_t lead_blocks = std::max<size_t>(1, kLead / pbytes);
+  const int device = h->cfg.device_id;
+  std::thread feeder;
+  if (ok) ok = hipMemsetAsync(h->x, 0, pbytes, h->stream) == hipSuccess;
+  if (ok) {
+    filler(10 * fill_1ms);                                            // the ramp of a rested device, run under the first allocations
+    feeder = std::thread([&feed, seconds, pbytes, budget, lead_blocks, device]() {
+      const bool dev_ok = hipSetDevice(device) == hipSuccess;
+      for (;;) {
+        {
+          std::unique_lock<std::mutex> lk(feed.m);
+          feed.cv.wait(lk, [&] { return feed.stop || feed.blocks.size() < feed.taken + lead_blocks; });
+          if (feed.stop || !dev_ok || (int)feed.blocks.size() >= kMaxBlocks || (feed.blocks.size() + 2) * pbytes > budget ||
+              seconds() > kMaxSeconds)
+            break;
+        }
+        void* b = nullptr;
+        const double tm = seconds();
+        const bool got = hipMalloc(&b, pbytes) == hipSuccess;
+        const double dt = seconds() - tm;
+        std::lock_guard<std::mutex> lk(feed.m);
+        feed.malloc_seconds += dt;
+        if (!got) { (void)hipGetLastError(); break; }
+        feed.blocks.push_back(b);
+        feed.cv.notify_all();
+      }
+      std::lock_guard<std::mutex> lk(feed.m);
+      feed.done = true;
+      feed.cv.notify_all();
+    });
+  }
   void* best = nullptr;
   float best_ms = 0.f, worst_ms = 0.f;
-  int timed = 0, since_better = 0;
-  size_t since_timed = kStride;                                       // the first block is timed
-  if (ok) ok = hipMemsetAsync(h->x, 0, pbytes, h->stream) == hipSuccess;
-  while (ok && (int)blocks.size() < kMaxBlocks && (blocks.size() + 2) * pbytes <= budget) {
-    // (the clock is read before every allocation too: right after the process has released gigabytes -- a create / destroy loop --
-    // hipMalloc itself can take milliseconds per block until the release has gone through)
-    if (seconds() > kMaxSeconds) break;
+  int timed = 0;
+  size_t last = 0, best_at = 0;                                       // blocks.size() at the last / at the best reading
+  st.outcome = PIC_PLACED_MEMORY;                                     // (the feeder ran into the block or memory limit, or hipMalloc failed)
+  while (ok) {
     void* b = nullptr;
-    if (hipMalloc(&b, pbytes) != hipSuccess) break;
-    blocks.push_back(b);
-    since_timed += pbytes;
-    if (since_timed < kStride && blocks.size() > 3) continue;         // (the first blocks are all timed: recycled memory often pairs at once)
-    since_timed = 0;
+    {
+      std::unique_lock<std::mutex> lk(feed.m);
+      feed.cv.wait(lk, [&] { return feed.done || feed.blocks.size() > last; });
+      if (feed.blocks.size() == last) break;                          // the feeder has stopped and every block it made has been looked at
+      last = feed.taken = feed.blocks.size();                         // the NEWEST block: the walk moves at the allocator's speed
+      b = feed.blocks.back();
+      feed.cv.notify_all();
+    }
+    if (seconds() > kMaxSeconds) { st.outcome = PIC_PLACED_TIMEOUT; break; }
     float ms = 0.f;
-    // (the first pair is timed twice and the first reading dropped: after an idle spell the clocks are still ramping, the
-    // reading comes out 5-10 % slow, and as "the slowest seen" it made the next pair of the SAME kind look like a find)
-    if (timed == 0) ok = pair_ms(b, &ms);
-    if (ok) ok = pair_ms(b, &ms);
+    ok = pair_ms(b, &ms);
     if (!ok) break;
     ++timed;
-    if (!best || ms < best_ms) { best = b; best_ms = ms; since_better = 0; } else ++since_better;
+    if (!best || ms < best_ms) { best = b; best_ms = ms; best_at = last; }
     if (ms > worst_ms) worst_ms = ms;
-    if (worst_ms >= kGain * best_ms) break;                           // a fast pair, known to be one
-    if (since_better >= kPatience || seconds() > kMaxSeconds) break;
+    if (worst_ms >= kGain * best_ms) { st.outcome = PIC_PLACED_FOUND; break; }       // a fast pair, known to be one
+    if ((last - best_at) * pbytes >= kPatience) { st.outcome = PIC_PLACED_PATIENCE; break; }
   }
+  if (feeder.joinable()) {
+    {
+      std::lock_guard<std::mutex> lk(feed.m);
+      feed.stop = true;
+      feed.cv.notify_all();
+    }
+    feeder.join();
+  }
+  if (st.outcome == PIC_PLACED_MEMORY && seconds() > kMaxSeconds) st.outcome = PIC_PLACED_TIMEOUT;    // (the feeder's own clock check)
+  (void)hipStreamSynchronize(h->stream);
   if (e0) hipEventDestroy(e0);
   if (e1) hipEventDestroy(e1);
   (void)hipGetLastError();
+  std::vector<void*>& blocks = feed.blocks;
   if (!best) {                                                        // nothing could be timed: any block will do
     if (blocks.empty()) {
       e = hipMalloc(&best, pbytes);
@@ -640,15 +725,19 @@ hipError_t alloc_particles(pic_handle* h, size_t pbytes) {
       best = blocks.front();
     }
   }
+  const double tf = seconds();
   for (void* b : blocks)
     if (b != best) hipFree(b);
+  st.free_seconds = seconds() - tf;
   h->v = best;
-  h->place_tried = timed > 0 ? timed : 1;
+  st.blocks = (int)blocks.size();
+  st.pairs_timed = timed;
+  st.malloc_seconds = feed.malloc_seconds;
   if (timed > 0) {
-    h->place_gbs[0] = gb_per_ms / best_ms;
-    h->place_gbs[1] = gb_per_ms / worst_ms;
+    st.kept_gbytes_per_s = gb_per_ms / best_ms;
+    st.slowest_gbytes_per_s = gb_per_ms / worst_ms;
   }
-  h->place_seconds = seconds();
+  st.seconds = seconds();
   return hipSuccess;
 }
 
@@ -683,6 +772,15 @@ int pic_create(const pic_config* cfg, pic_handle** out) {
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
     return fail(nullptr, PIC_EHIP, "pic_create: no HIP device visible (this library has no CPU path)");
   if (cfg->device_id < 0 || cfg->device_id >= ndev) return fail(nullptr, PIC_EINVAL, "pic_create: bad device_id");
+  {
+    // the library holds gfx950 code objects only: say so here, not as hipErrorNoBinaryForGpu at the first launch
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, cfg->device_id) != hipSuccess)
+      return fail(nullptr, PIC_EHIP, "pic_create: hipGetDeviceProperties failed");
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+      return fail(nullptr, PIC_EHIP, std::string("pic_create: device ") + std::to_string(cfg->device_id) + " is " + prop.gcnArchName +
+                                         ": libpicstep.so is built for gfx950 (MI355X) only");
+  }
 
   pic_handle* h = new (std::nothrow) pic_handle();
   if (!h) return fail(nullptr, PIC_ENOMEM, "pic_create: out of host memory");
@@ -916,10 +1014,16 @@ int pic_schedule(pic_handle* h) { return h ? (h->resident ? 1 : 0) : PIC_EINVAL;
 int pic_placement_info(pic_handle* h, int* candidates, double* kept_gbytes_per_s, double* slowest_gbytes_per_s,
                        double* seconds) {
   if (!h) return PIC_EINVAL;
-  if (candidates) *candidates = h->place_tried;
-  if (kept_gbytes_per_s) *kept_gbytes_per_s = h->place_gbs[0];
-  if (slowest_gbytes_per_s) *slowest_gbytes_per_s = h->place_gbs[1];
-  if (seconds) *seconds = h->place_seconds;
+  if (candidates) *candidates = h->place.pairs_timed > 0 ? h->place.pairs_timed : 1;
+  if (kept_gbytes_per_s) *kept_gbytes_per_s = h->place.kept_gbytes_per_s;
+  if (slowest_gbytes_per_s) *slowest_gbytes_per_s = h->place.slowest_gbytes_per_s;
+  if (seconds) *seconds = h->place.seconds;
+  return PIC_OK;
+}
+
+int pic_placement_stats(pic_handle* h, pic_placement* out) {
+  if (!h || !out) return PIC_EINVAL;
+  *out = h->place;
   return PIC_OK;
 }
 
@@ -933,13 +1037,13 @@ int pic_sync(pic_handle* h) {
 int pic_set_particles(pic_handle* h, const void* x, const void* v, int mem_kind) {
   if (!h || !x || !v) return fail(h, PIC_EINVAL, "pic_set_particles: null argument");
   HIPCHK(h, hipSetDevice(h->cfg.device_id));
+  drop_cached_deposits(h);      // first: an upload that fails half way has still changed x, and no cached deposit may outlive that
   int rc = upload_positions(h, h->x, x, mem_kind);
   if (rc) return rc;
   rc = upload(h, h->v, v, mem_kind);
   if (rc) return rc;
   if (mem_kind == PIC_HOST) HIPCHK(h, hipStreamSynchronize(h->stream));
   h->has_state = true;
-  drop_cached_deposits(h);
   return PIC_OK;
 }
 
@@ -1065,7 +1169,12 @@ static int advance(pic_handle* h, const StepControl& sc, int nsteps, double* his
     ring_retire(h, h->q_slot);       // the ring's q1 deposit belongs to the particles before these steps
     ring_retire(h, h->stage_slot);
     h->q_slot = h->stage_slot = -1;
-    HIPCHK(h, hipGetLastError());
+    // the q1 mesh and the carried cells the kernel leaves behind are valid only if the launch went out: after a failed one the
+    // next call must deposit q1 itself instead of taking over an unwritten block
+    const hipError_t e = launch_status(h);
+    h->res_q1_valid = e == hipSuccess;
+    h->res_carry_valid = e == hipSuccess && h->res_carry != nullptr;
+    HIPCHK(h, e);
     return PIC_OK;
   }
   const size_t act_row = (size_t)E * 2 * sc.ctl.M;
@@ -1103,7 +1212,7 @@ static int advance(pic_handle* h, const StepControl& sc, int nsteps, double* his
   h->hist_row = h->post_hist_row = nullptr;
   h->fb = Feedback{};
   h->inline_act = nullptr;
-  HIPCHK(h, hipGetLastError());
+  HIPCHK(h, launch_status(h));
   return PIC_OK;
 }
 
@@ -1271,7 +1380,7 @@ static int enqueue_observe(pic_handle* h, bool scalars, size_t* pitch) {
   const int E = h->cfg.num_envs;
   const size_t row = (size_t)h->cfg.N * h->esz;
   *pitch = row;
-  if (2 * row * E > kTinyState) {
+  if (2 * row * E > kTinyState || 2 * E > 65535) {      // (the kernel below numbers environments in grid.y: at most 65535 rows)
     // the arrays as they lie on the device, padding included, in plain copies (a strided copy command runs at a seventh of the rate)
     const size_t block = (size_t)E * h->ld * h->esz;
     *pitch = (size_t)h->ld * h->esz;
@@ -1293,6 +1402,7 @@ static int enqueue_observe(pic_handle* h, bool scalars, size_t* pitch) {
     hipLaunchKernelGGL(observe_kernel<float>, grid, dim3(BLOCK), 0, h->stream, static_cast<const float*>(h->x),
                        static_cast<const float*>(h->v), (long long)h->cfg.N, (long long)h->ld, E, static_cast<float*>(h->h_part),
                        h->KE, scalars ? h->h_scal : nullptr);
+  HIPCHK(h, hipGetLastError());
   return PIC_OK;
 }
 // staging -> the caller's [num_envs][N] arrays

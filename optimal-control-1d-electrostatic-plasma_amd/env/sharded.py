@@ -47,15 +47,22 @@ class ShardedPIC:
 
             def env_factory(num_envs, N, N_mesh, **kw):
                 return BatchedPIC(num_envs, N, N_mesh, **kw)
+        # The device is resolved ONCE, here: the ordinal that is checked is the ordinal the handle is created on.  (Left to the
+        # factory's default a rank that had only called torch.cuda.set_device(LOCAL_RANK) would pass the check below with its
+        # current device and then build its handle on device 0 -- the very sharing the check refuses.)
+        nccl = dist.is_initialized() and dist.get_backend() == "nccl"
         if device is not None:
-            env_kwargs["device"] = device
-        if dist.is_initialized() and dist.get_backend() == "nccl" and self.world > 1:
-            import socket
+            env_kwargs["device"] = int(device)
+        elif "device" not in env_kwargs and nccl:
             import torch
-            mine = (socket.gethostname(), int(env_kwargs.get("device", torch.cuda.current_device())))
+            env_kwargs["device"] = int(torch.cuda.current_device())
+        if nccl and self.world > 1:
+            import socket
+            mine = (socket.gethostname(), int(env_kwargs["device"]))
             every = [None] * self.world
             dist.all_gather_object(every, mine)
             check_one_device_per_rank(every)
+        self.device = env_kwargs.get("device", 0)
         if env_factory_is_default:
             env_kwargs.setdefault("env_index_base", self.lo)      # device sampler keyed by the GLOBAL environment index
         self.env = env_factory(self.num_local, N, N_mesh, **env_kwargs)

@@ -12,19 +12,31 @@ import numpy as np
 
 from .. import _abi
 
-_probes = {}
+import threading
+
+# One cache PER THREAD: calls on a handle are not re-entrant (include/picstep.h), and two threads evaluating fields of states of
+# the same shape would otherwise meet on one probe handle.  Handles own device memory, so each cache stays small.
+_local = threading.local()
 _MAX_PROBES = 8
 
 
+def _probe_cache():
+    cache = getattr(_local, "probes", None)
+    if cache is None:
+        cache = _local.probes = {}
+    return cache
+
+
 def probe_handle(N, N_mesh, L, n0, interpol="CIC", device=0):
-    """Single-environment float64 handle used only to evaluate fields of caller-supplied positions."""
+    """Single-environment float64 handle used only to evaluate fields of caller-supplied positions (this thread's own)."""
     key = (int(N), int(N_mesh), float(L), float(n0), str(interpol), int(device))
-    h = _probes.get(key)
+    probes = _probe_cache()
+    h = probes.get(key)
     if h is None:
-        while len(_probes) >= _MAX_PROBES:            # handles own device memory: keep the cache small
-            _probes.pop(next(iter(_probes))).close()
+        while len(probes) >= _MAX_PROBES:
+            probes.pop(next(iter(probes))).close()
         h = _abi.Handle(key[0], key[1], 1, key[2], key[3], 1.0, 5.0, "float64", None, key[4], key[5])
-        _probes[key] = h
+        probes[key] = h
     return h
 
 

@@ -217,5 +217,108 @@ def main():
          ts_init_state=ts.get_init_state(), bt_init_state=bt.get_init_state())
 
 
+def composed_loops(only=()):
+    """G12-G14 (round 4): the reference's own LOOPS around the step, run as it writes them -- the closed feedback loop of
+    run_feedback.py:130-168, PIC.simulate (src/env/pic.py:175-223) and the behaviour-cloning rollout of
+    src/control/rl/ddpg.py:364-381 with its hard-coded spectrum arguments (n0 = 1, L = 50, Ng = 250)."""
+    from src.env.pic import PIC
+    from src.env.dist import BumpOnTail, TwoStream
+    from src.control.actuator import E_field
+    from src.control.rl.reward import Reward
+    from src.interpret.spectrum import compute_E_k_spectrum
+    L = 50.0
+
+    def want(tag):
+        return not only or tag in only
+
+    # ---- G12: run_feedback.py:130-168, its defaults (two-stream, N = 5000, Ng = 250, dt = 0.1) with max_mode = 5 ----------
+    if want("g12"):
+        N, Ng, mm, K = 5000, 250, 5, 50
+        np.random.seed(47)
+        sim = PIC(N=N, N_mesh=Ng, n0=1.0, L=L, dt=0.1, tmin=0.0, tmax=50.0, gamma=5.0, A=0.1, n_mode=2, interpol="CIC",
+                  init_dist=TwoStream(v0=3.0, sigma=1.0, n_samples=N, L=L))
+        out = dict(L=L, Ng=Ng, N=N, n0=1.0, dt=sim.dt, max_mode=mm, x_init=sim.x.copy(), v_init=sim.v.copy(),
+                   init_state=sim.init_dist.get_init_state())
+        actuator = E_field(L, Ng, mm)
+        reward = Reward(sim.init_dist.get_init_state(), Ng, L, -25.0, 25.0, 1.0, 1.0, 1.0)
+        cc, cs, Hs, PEs, rs, kl, ee, ie, fields = [], [], [], [], [], [], [], [], []
+        for k in range(1, K + 1):
+            _, Eks = compute_E_k_spectrum(1.0, L, L / Ng, Ng, sim.get_state(), False)
+            Eks = Eks[1:mm + 1, :]
+            actuator.update_E((-1) * np.real(Eks), (+1) * np.imag(Eks))
+            coeffs = np.concatenate([actuator.coeff_cos.ravel(), actuator.coeff_sin.ravel()])
+            E_external = actuator.compute_E()
+            sim.update_state(E_external)
+            cc.append(actuator.coeff_cos.ravel().copy()); cs.append(actuator.coeff_sin.ravel().copy())
+            fields.append(E_external[:, 0].copy())
+            Hs.append(sim.get_energy()); PEs.append(sim.get_electric_energy())
+            kl.append(reward.compute_kl_divergence(sim.get_state()))
+            ee.append(reward.compute_electric_energy(sim.get_state()))
+            ie.append(reward.compute_input_energy(coeffs))
+            rs.append(reward.compute_reward(sim.get_state(), E_external))     # the mesh field as "action" (run_feedback.py:160)
+            if k in (1, 10, 50):
+                out[f"x_{k}"] = sim.x.copy(); out[f"v_{k}"] = sim.v.copy(); out[f"E_mesh_{k}"] = sim.E_mesh.copy()
+                out[f"n_{k}"] = sim.n.copy()
+        out.update(coeff_cos=np.array(cc), coeff_sin=np.array(cs), E_external=np.array(fields), H=np.array(Hs), PE=np.array(PEs),
+                   reward=np.array(rs), cost_kl=np.array(kl), cost_ee=np.array(ee), cost_ie=np.array(ie))
+        save("g12_feedback_two_stream_N5000_Ng250", **out)
+
+    # ---- G13: PIC.simulate with and without a field trajectory --------------------------------------------------------------
+    if want("g13"):
+        N, Ng = 3000, 128
+        np.random.seed(48)
+        sim = PIC(N=N, N_mesh=Ng, n0=1.0, L=L, dt=0.1, tmin=0.0, tmax=1.2, gamma=5.0, A=0.1, n_mode=2, interpol="CIC",
+                  init_dist=TwoStream(v0=3.0, sigma=1.0, n_samples=N, L=L))
+        Nt = int(np.ceil((sim.tmax - sim.tmin) / sim.dt))
+        arng = np.random.default_rng(1348)
+        act = E_field(L, Ng, 3)
+        traj = [act.compute_E(arng.uniform(-1.25, 1.25, 3), arng.uniform(-1.25, 1.25, 3)) for _ in range(Nt)]
+        out = dict(L=L, Ng=Ng, N=N, n0=1.0, dt=sim.dt, tmin=0.0, tmax=1.2, Nt=Nt, x_init=sim.x.copy(), v_init=sim.v.copy(),
+                   E_external_traj=np.array([t[:, 0] for t in traj]))
+        snapshot, E, PE = sim.simulate(traj)
+        out.update(snapshot=snapshot, E=E, PE=PE, E_mesh_final=sim.E_mesh.copy())
+        np.random.seed(49)
+        N2, Ng2 = 2000, 64
+        sim = PIC(N=N2, N_mesh=Ng2, n0=1.0, L=L, dt=0.1, tmin=0.0, tmax=0.8, gamma=5.0, A=0.1, n_mode=2, interpol="TSC",
+                  init_dist=BumpOnTail(a=0.2, v0=3.0, sigma=1.0, n_samples=N2, L=L))
+        out.update(free_N=N2, free_Ng=Ng2, free_tmax=0.8, free_x_init=sim.x.copy(), free_v_init=sim.v.copy())
+        snapshot, E, PE = sim.simulate(None)
+        out.update(free_snapshot=snapshot, free_E=E, free_PE=PE)
+        save("g13_simulate", **out)
+
+    # ---- G14: behaviour-cloning rollout, ddpg.py:364-381 (the spectrum call is hard-coded to n0 = 1, L = 50, Ng = 250) ------
+    if want("g14"):
+        out = dict(L=L)
+        for tag, N, Ng, seed in (("a", 4000, 250, 50), ("b", 3000, 200, 51)):          # b: the environment's own mesh is NOT 250
+            np.random.seed(seed)
+            env = PIC(N=N, N_mesh=Ng, n0=1.0, L=L, dt=0.1, tmin=0.0, tmax=50.0, gamma=5.0, A=0.1, n_mode=2, interpol="CIC",
+                      init_dist=BumpOnTail(a=0.2, v0=3.0, sigma=1.0, n_samples=N, L=L))
+            actuator = E_field(env.L, env.N_mesh, 5)
+            reward_cls = Reward(env.init_dist.get_init_state(), env.N_mesh, env.L, -25.0, 25.0, env.n0, 1.0, 0.5)
+            max_mode, K = 5, 25
+            out.update({f"{tag}_N": N, f"{tag}_Ng": Ng, f"{tag}_dt": env.dt, f"{tag}_x_init": env.x.copy(),
+                        f"{tag}_v_init": env.v.copy(), f"{tag}_init_state": env.init_dist.get_init_state()})
+            actions, rewards = [], []
+            for idx_t in range(K):
+                state = env.get_state()
+                _, Eks = compute_E_k_spectrum(1.0, 50.0, 50.0 / 250, 250, state, False)
+                Eks = Eks[1:max_mode + 1, :]
+                actuator.update_E((-1) * np.real(Eks), (+1) * np.imag(Eks))
+                action = np.concatenate([actuator.coeff_cos.ravel(), actuator.coeff_sin.ravel()])
+                env.update_state(E_external=actuator.compute_E())
+                actions.append(action)
+                rewards.append(reward_cls.compute_reward(state, action))      # on the PRE-step state
+            out.update({f"{tag}_actions": np.array(actions), f"{tag}_reward": np.array(rewards), f"{tag}_x_final": env.x.copy(),
+                        f"{tag}_v_final": env.v.copy(), f"{tag}_E_mesh_final": env.E_mesh.copy(), f"{tag}_steps": K})
+        save("g14_bc_rollout", **out)
+
+
 if __name__ == "__main__":
-    main()
+    # `make_golden.py g12 g13 g14` regenerates only the named composed-loop fixtures; no argument = everything
+    sel = tuple(a for a in sys.argv[1:] if a in ("g12", "g13", "g14"))
+    if sel:
+        _import_reference()
+        composed_loops(sel)
+    else:
+        main()
+        composed_loops()

@@ -109,7 +109,11 @@ def test_no_kernel_spills_registers(lib_path):
     assert os.path.getmtime(_build.RESOURCES) >= os.path.getmtime(lib_path) - 120, "resource report older than the library"
     rep = json.load(open(_build.RESOURCES))
     assert len(rep) > 100
-    spilled = {k: v["scratch_bytes_per_lane"] for k, v in rep.items() if v["scratch_bytes_per_lane"]}
+    # a report that could not be parsed (a compiler update rewording its remarks) must fail here, not pass as "no scratch"
+    unparsed = {k: v for k, v in rep.items()
+                if any(v.get(f) is None for f in ("scratch_bytes_per_lane", "vgprs", "waves_per_simd", "lds_bytes_per_block"))}
+    assert not unparsed, unparsed
+    spilled = {k: v["scratch_bytes_per_lane"] for k, v in rep.items() if v["scratch_bytes_per_lane"] != 0}
     assert not spilled, spilled
     for k, v in rep.items():
         if "sweep_kernel" in k:
@@ -117,6 +121,51 @@ def test_no_kernel_spills_registers(lib_path):
         m = re.search(r"resident_kernel.*Li(\d+)ELi8ELb([01])E", k)
         if m:     # the kernel without carried cells shares a CU with a second workgroup up to 10 particles per lane (picstep.hip: res_lean)
             assert v["vgprs"] <= (128 if m.group(2) == "0" and int(m.group(1)) <= 10 else 256), (k, v)
+
+
+def test_placement_struct_layout_matches_header():
+    hdr = open(os.path.join(ROOT, "include", "picstep.h")).read()
+    body = hdr[hdr.index("typedef struct {\n  int32_t pairs_timed;"):hdr.index("} pic_placement;")]
+    fields = [f for decl in re.findall(r"^\s*(?:int32_t|double)\s+([\w, ]+);", body, re.M) for f in decl.replace(" ", "").split(",")]
+    assert fields == [f[0] for f in _abi._Placement._fields_], fields
+    assert ctypes.sizeof(_abi._Placement) == 4 * 4 + 6 * 8
+
+
+def test_sharded_env_resolves_its_device_once(monkeypatch):
+    """ShardedPIC without `device`: the ordinal checked across ranks must be the ordinal the handle is created on (a rank that
+    only called torch.cuda.set_device(LOCAL_RANK) used to pass the check with its current device and build on device 0)."""
+    import torch
+    import torch.distributed as dist
+    from ocplasma_amd.env import sharded
+    monkeypatch.setattr(dist, "is_initialized", lambda: True)
+    monkeypatch.setattr(dist, "get_backend", lambda *a: "nccl")
+    monkeypatch.setattr(dist, "get_world_size", lambda *a: 2)
+    monkeypatch.setattr(dist, "get_rank", lambda *a: 1)
+    monkeypatch.setattr(torch.cuda, "current_device", lambda: 5)
+    seen = {}
+
+    def all_gather_object(out, mine):
+        seen["mine"] = mine
+        out[0], out[1] = ("host", 4), mine
+
+    monkeypatch.setattr(dist, "all_gather_object", all_gather_object)
+
+    def factory(num_envs, N, Ng, **kw):
+        seen["kw"] = kw
+        return object()
+
+    sh = sharded.ShardedPIC(6, 100, 16, env_factory=factory)
+    assert seen["mine"][1] == 5 and seen["kw"]["device"] == 5 and sh.device == 5
+    sh = sharded.ShardedPIC(6, 100, 16, env_factory=factory, device=3)
+    assert seen["mine"][1] == 3 and seen["kw"]["device"] == 3
+    # two ranks that resolve to the same device of the same host are refused
+
+    def clash(out, mine):
+        out[0], out[1] = mine, mine
+
+    monkeypatch.setattr(dist, "all_gather_object", clash)
+    with pytest.raises(RuntimeError, match="both drive device"):
+        sharded.ShardedPIC(6, 100, 16, env_factory=factory)
 
 
 def test_config_struct_layout_matches_header():

@@ -170,3 +170,62 @@ def test_g9_spectrum():
     snap = np.concatenate([np.concatenate([d["x_10"], d["v_10"]], 0), np.concatenate([d["x_100"], d["v_100"]], 0)], 1)
     ks, Ek = po.E_k_spectrum(1.0, 50.0, 50.0 / 250, 250, snap, False)
     assert np.allclose(ks[:8], g["ks"], rtol=1e-14) and rel_err(Ek[:8], g["Ek"]) < 1e-11
+
+
+# ---- the reference's loops around the step (G12-G14, round 4) ----------------------------------
+def test_g12_feedback_loop():
+    """run_feedback.py:130-168 restated on the oracle: spectrum -> (-Re, +Im) -> actuator field -> step, 50 times."""
+    g = load_golden("g12_feedback_two_stream_N5000_Ng250")
+    L, Ng, N, mm = float(g["L"]), int(g["Ng"]), int(g["N"]), int(g["max_mode"])
+    sim = po.OraclePIC(g["x_init"], g["v_init"], Ng, L=L, dt=float(g["dt"]), perturb=False, faithful=False)
+    for k in range(1, 51):
+        _, Ek = po.E_k_spectrum(1.0, L, L / Ng, Ng, sim.get_state(), False)
+        Ek = Ek[1:mm + 1, :]
+        cc, cs = (-1) * np.real(Ek), (+1) * np.imag(Ek)
+        assert rel_err(cc.ravel(), g["coeff_cos"][k - 1]) < 1e-9 and rel_err(cs.ravel(), g["coeff_sin"][k - 1]) < 1e-9
+        field = po.actuator_field(L, Ng, mm, cc, cs)
+        sim.update_state(field)
+        assert abs(sim.get_energy() / g["H"][k - 1] - 1) < 1e-12
+        state = sim.get_state()
+        assert abs(po.reward_electric_energy(state, None, Ng, L, 1.0) / g["cost_ee"][k - 1] - 1) < 1e-9
+        r = max(1.0 - po.reward_electric_energy(state, None, Ng, L, 1.0), 0) + max(1.0 - po.input_energy(field, L) / (10 * L / 4), 0)
+        assert abs(r - g["reward"][k - 1]) < 1e-9
+        if k in (1, 10, 50):
+            assert rel_err(sim.x, g[f"x_{k}"]) < 1e-11 and rel_err(sim.v, g[f"v_{k}"]) < 1e-10
+            assert rel_err(sim.E_mesh, g[f"E_mesh_{k}"]) < 1e-9
+
+
+def test_g13_simulate():
+    """PIC.simulate (pic.py:175-223) as a loop of oracle steps: initial column, Nt steps under the trajectory's fields."""
+    g = load_golden("g13_simulate")
+    L = float(g["L"])
+    for prefix, interpol, fields in (("", "CIC", g["E_external_traj"]), ("free_", "TSC", None)):
+        N = int(g[prefix + "N"]) if prefix else int(g["N"])
+        Ng = int(g[prefix + "Ng"]) if prefix else int(g["Ng"])
+        want = g[prefix + "snapshot"]
+        sim = po.OraclePIC(g[prefix + "x_init"], g[prefix + "v_init"], Ng, L=L, dt=0.1, interpol=interpol, perturb=False,
+                           faithful=False)
+        assert np.array_equal(sim.get_state()[:, 0], want[:, 0])
+        assert abs(sim.get_energy() / g[prefix + "E"][0] - 1) < 1e-13
+        for k in range(1, want.shape[1]):
+            sim.update_state(None if fields is None else fields[k - 1].reshape(-1, 1))
+            assert rel_err(sim.get_state()[:, 0], want[:, k]) < 1e-11
+            assert abs(sim.get_energy() / g[prefix + "E"][k] - 1) < 1e-12
+            assert abs(sim.get_electric_energy() / g[prefix + "PE"][k] - 1) < 1e-10
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_g14_bc_rollout(tag):
+    """ddpg.py:364-381: spectrum with the hard-coded (n0, L, Ng) = (1, 50, 250), reward on the pre-step state."""
+    g = load_golden("g14_bc_rollout")
+    L, Ng = float(g["L"]), int(g[f"{tag}_Ng"])
+    sim = po.OraclePIC(g[f"{tag}_x_init"], g[f"{tag}_v_init"], Ng, L=L, dt=float(g[f"{tag}_dt"]), perturb=False, faithful=False)
+    for k in range(int(g[f"{tag}_steps"])):
+        state = sim.get_state()
+        _, Ek = po.E_k_spectrum(1.0, 50.0, 50.0 / 250, 250, state, False)
+        Ek = Ek[1:6, :]
+        action = np.concatenate([((-1) * np.real(Ek)).ravel(), ((+1) * np.imag(Ek)).ravel()])
+        assert np.max(np.abs(action - g[f"{tag}_actions"][k])) < 1e-9 * np.max(np.abs(g[f"{tag}_actions"]))
+        sim.update_state(po.actuator_field(L, Ng, 5, action[:5], action[5:]))
+        assert abs(po.reward_value(state, action, Ng, L, 1.0, alpha=1.0, beta=0.5) - g[f"{tag}_reward"][k]) < 1e-9
+    assert rel_err(sim.x, g[f"{tag}_x_final"]) < 1e-11 and rel_err(sim.E_mesh, g[f"{tag}_E_mesh_final"]) < 1e-9
