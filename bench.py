@@ -57,7 +57,7 @@ def synth_bump_on_tail_device(torch, num_envs, N, L, dtype, device, seed, a=0.2,
     return x.to(dtype).contiguous(), v.to(dtype).contiguous()
 
 
-PMC_SUMMARY = "r3_summary.json"          # committed rocprofv3 evidence of this round (profiles/collect.sh)
+PMC_SUMMARY = "r4_summary.json"          # committed rocprofv3 evidence of this round (profiles/collect.sh)
 # VALU issue ceiling for the resident schedule's roofline, in 1e9 wave-instructions per second: 256 CUs x 4 SIMDs at the 2.4 GHz
 # peak clock, one wave-instruction per SIMD every 2 cycles for 32-bit operations (a SIMD-32 takes a 64-lane wave in two
 # passes) and every 4 cycles for the float64 operations that make up the float64 push (78.6 TFLOP/s FP64 vector = 16 FMA
@@ -83,7 +83,7 @@ def pmc_valu_per_particle_step(args, N, Ng):
     if not os.path.exists(path):
         return None, None
     table = json.load(open(path)).get("resident_valu_wave_insts_per_particle_step", {})
-    key = f"{args.dtype}/{args.positions}/N={N}/Ng={Ng}"
+    key = f"{args.dtype}/{args.positions}/N={N}/Ng={Ng}" + ("/history" if args.history else "")     # (every refresh made: more work)
     return table.get(key), f"profiles/{PMC_SUMMARY}: SQ_INSTS_VALU per launch / particle-steps per launch, {key}"
 
 
@@ -322,9 +322,23 @@ def main():
         env.profile(False)
         return prof, ms
 
+    def setup_views_and_collectives():
+        """Everything the timed region and its collectives do for the first time, done once untimed: the zero-copy views, RCCL's
+        set-up of each collective.  In the default order this runs BEFORE the measured regions, so that nothing but the W warm-up
+        steps and a barrier stands between the event pass and the timed steps (the device would rest for milliseconds here)."""
+        if cdev != "cpu":
+            env.sync()
+            env.rewards_torch()
+        if dist is not None:
+            w = env.rewards_torch() if cdev != "cpu" else torch.as_tensor(env.rewards(), device=cdev)
+            dist.all_gather([torch.empty_like(w) for _ in range(world)], w)
+            dist.all_reduce(torch.zeros(1, device=cdev, dtype=torch.float64), op=dist.ReduceOp.MAX)
+            dist.barrier()
+
     psteps = args.steps if args.profile_steps < 0 else args.profile_steps
     cold = steady = prof = ms_per_step_events = None
     if args.order == "warm":
+        setup_views_and_collectives()
         # The regions this script measures anyway, in front of the headline one (module docstring): every rank runs them, so that
         # all devices of a multi-GPU run are in the same state when the timed region starts.
         cold = {"steps": args.steps, "ms_per_step": timed_region(args.steps)}
@@ -334,16 +348,8 @@ def main():
             prof, ms_per_step_events = event_pass()
 
     run_steps(args.warmup)
-    if cdev != "cpu":
-        env.sync()
-        env.rewards_torch()          # builds the zero-copy views once, outside the timed region
-    if dist is not None:
-        # RCCL sets a collective up on its first use: run the ones of the timed region once, untimed
-        w = env.rewards_torch() if cdev != "cpu" else torch.as_tensor(env.rewards(), device=cdev)
-        dist.all_gather([torch.empty_like(w) for _ in range(world)], w)
-        dist.all_reduce(torch.zeros(1, device=cdev, dtype=torch.float64), op=dist.ReduceOp.MAX)
-        if args.order == "warm" and args.warmup > 0:
-            run_steps(args.warmup)   # the set-up of the collectives let the device rest: the W warm-up steps once more, behind it
+    if args.order == "cold":
+        setup_views_and_collectives()
     barrier()
     t0 = time.perf_counter()
     run_steps(args.steps)

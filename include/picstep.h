@@ -41,7 +41,7 @@ enum { PIC_PLACE_AUTO = 0,                   /* large states: look for x and v i
 enum { PIC_HOST = 0, PIC_DEVICE = 1 };       /* where a caller buffer lives                   */
 enum { PIC_PLACED_NONE = 0,                  /* pic_placement.outcome: no search (small state or PIC_PLACE_OFF)                    */
        PIC_PLACED_FOUND = 1,                 /* the pair kept streams >= 10 % faster than the slowest pair seen                    */
-       PIC_PLACED_PATIENCE = 2,              /* fourteen timed pairs without an improvement: all alike, the best of them kept      */
+       PIC_PLACED_PATIENCE = 2,              /* 42 GiB walked without an improvement: all alike, the best of them kept             */
        PIC_PLACED_TIMEOUT = 3,               /* 100 ms spent: the best pair seen so far kept                                       */
        PIC_PLACED_MEMORY = 4 };              /* a third of the free memory held (or an allocation failed): the best pair seen kept */
 
@@ -273,9 +273,11 @@ int pic_schedule(pic_handle* h);
 
 /* Particle states of 256 MB and more: x and v are two allocations, and pic_create times a streaming pass over (x, candidate
  * block for v) for a series of candidate blocks: on MI355X two arrays stream together at 6.05 TB/s when they lie in different
- * 32 GiB regions of HBM and at 5.25 TB/s when they share one.  The search stops as soon as the best pair seen is
- * 10 % faster than the slowest seen, after fourteen timed pairs (42 GiB, more than a 32 GiB region) without an improvement, after 100 ms, or when a third of the
- * device's free memory is held -- whichever comes first; no absolute rate enters.
+ * 32 GiB regions of HBM and at 5.25 TB/s when they share one.  The search stops sixteen readings after the best pair
+ * seen is 10 % faster than the slowest seen (keeping the best of all), after 42 GiB walked without an improvement (more than a
+ * 32 GiB region), after 100 ms, or when a third of the device's free memory is held -- whichever comes first; no absolute rate
+ * enters.  Candidate blocks are allocated by a thread of the call's own while the calling thread times them (hipMalloc of memory
+ * the device hands out for the first time costs 1.3 ms per 512 MB); it is joined before pic_create returns.
  * What a co-resident allocator (torch's caching allocator, another handle on another thread or rank of the same device) sees:
  * while pic_create runs, blocks of the state's size are allocated one after the other and up to a third of the free memory is
  * held; all but x and v are freed before it returns.  An allocation made by someone else in that window can fail for lack of

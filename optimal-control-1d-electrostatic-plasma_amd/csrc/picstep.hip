@@ -567,8 +567,8 @@ const char* pic_last_error(pic_handle* h) { return h ? h->err.c_str() : g_create
 // it is paired with, not the candidate), which is why the search times WHOLE blocks, never windows of them.
 // For particle states that live in HBM (>= 256 MB) x and v are therefore two allocations: x first, then blocks of the same
 // size one after the other (they are laid down in sequence), and the pair (x, newest block) is timed with a streaming pass again
-// and again while the blocks keep coming.  The search is a policy on RATIOS, not on this part's numbers: it ends when the best
-// pair seen streams >= 10 % faster than the slowest one seen (the two kinds have been told apart and we hold a fast one), after
+// and again while the blocks keep coming.  The search is a policy on RATIOS, not on this part's numbers: it ends sixteen readings
+// after the best pair seen streams >= 10 % faster than the slowest one seen (the kinds have been told apart and we hold a fast one), after
 // 42 GiB walked without an improvement (more than a region, all pairs alike: nothing to gain on this device), after 100 ms, or
 // when a third of the free memory is held; everything but x and v is freed before pic_create returns.
 // pic_config.placement = PIC_PLACE_OFF skips it (x | v in one block).  Smaller states keep x | v in one block too (they sit in
@@ -588,6 +588,7 @@ struct BlockFeed {                                  // candidate blocks, allocat
   std::condition_variable cv;
   std::vector<void*> blocks;                        // in allocation order; only ever grown by the feeder
   size_t taken = 0;                                 // blocks.size() when the timing thread last took one
+  size_t lead = 1;                                  // the feeder stays at most this many blocks ahead of `taken`
   bool stop = false, done = false;
   double malloc_seconds = 0.0;
 };
@@ -602,6 +603,7 @@ hipError_t alloc_particles(pic_handle* h, size_t pbytes) {
   constexpr double kGain = 1.10;                    // best / slowest rate at which the search has found what it looks for
   constexpr size_t kPatience = (size_t)42 << 30;    // walked without an improvement before giving up: more than the 32 GiB a region
                                                     // spans (15 GiB gave up inside x's own region on some boxes: 1049 instead of 958 us)
+  constexpr int kMore = 16;                         // pairs timed beyond the first that passes kGain
   constexpr double kMaxSeconds = 0.100;
   constexpr int kMaxBlocks = 192;
   PlacementStats& st = h->place;
@@ -653,12 +655,13 @@ hipError_t alloc_particles(pic_handle* h, size_t pbytes) {
   if (ok) ok = hipMemsetAsync(h->x, 0, pbytes, h->stream) == hipSuccess;
   if (ok) {
     filler(10 * fill_1ms);                                            // the ramp of a rested device, run under the first allocations
-    feeder = std::thread([&feed, seconds, pbytes, budget, lead_blocks, device]() {
+    feed.lead = lead_blocks;
+    feeder = std::thread([&feed, seconds, pbytes, budget, device]() {
       const bool dev_ok = hipSetDevice(device) == hipSuccess;
       for (;;) {
         {
           std::unique_lock<std::mutex> lk(feed.m);
-          feed.cv.wait(lk, [&] { return feed.stop || feed.blocks.size() < feed.taken + lead_blocks; });
+          feed.cv.wait(lk, [&] { return feed.stop || feed.blocks.size() < feed.taken + feed.lead; });
           if (feed.stop || !dev_ok || (int)feed.blocks.size() >= kMaxBlocks || (feed.blocks.size() + 2) * pbytes > budget ||
               seconds() > kMaxSeconds)
             break;
@@ -680,7 +683,7 @@ hipError_t alloc_particles(pic_handle* h, size_t pbytes) {
   }
   void* best = nullptr;
   float best_ms = 0.f, worst_ms = 0.f;
-  int timed = 0;
+  int timed = 0, found_at = 0;
   size_t last = 0, best_at = 0;                                       // blocks.size() at the last / at the best reading
   st.outcome = PIC_PLACED_MEMORY;                                     // (the feeder ran into the block or memory limit, or hipMalloc failed)
   while (ok) {
@@ -691,16 +694,28 @@ hipError_t alloc_particles(pic_handle* h, size_t pbytes) {
       if (feed.blocks.size() == last) break;                          // the feeder has stopped and every block it made has been looked at
       last = feed.taken = feed.blocks.size();                         // the NEWEST block: the walk moves at the allocator's speed
       b = feed.blocks.back();
+      if (found_at > 0) feed.lead = 1;                                // (past the first find every block is looked at: fewer to give back)
       feed.cv.notify_all();
     }
-    if (seconds() > kMaxSeconds) { st.outcome = PIC_PLACED_TIMEOUT; break; }
+    if (seconds() > kMaxSeconds) {
+      if (st.outcome != PIC_PLACED_FOUND) st.outcome = PIC_PLACED_TIMEOUT;
+      break;
+    }
     float ms = 0.f;
     ok = pair_ms(b, &ms);
     if (!ok) break;
     ++timed;
     if (!best || ms < best_ms) { best = b; best_ms = ms; best_at = last; }
     if (ms > worst_ms) worst_ms = ms;
-    if (worst_ms >= kGain * best_ms) { st.outcome = PIC_PLACED_FOUND; break; }       // a fast pair, known to be one
+    if (worst_ms >= kGain * best_ms) {                                // a fast pair, known to be one ...
+      st.outcome = PIC_PLACED_FOUND;
+      // ... but there are more than two kinds (5.0-5.3 / 5.6-5.75 / 5.85-6.0 TB/s read on used devices, 0.983 / 0.970 / 0.963 ms per
+      // step at config 2), and the first pair 10 % above the slowest is often of the middle one: a reading costs 0.7 ms, so
+      // kMore further blocks are looked at and the best of all is kept
+      if (found_at == 0) found_at = timed;
+      if (timed - found_at >= kMore) break;
+      continue;
+    }
     if ((last - best_at) * pbytes >= kPatience) { st.outcome = PIC_PLACED_PATIENCE; break; }
   }
   if (feeder.joinable()) {

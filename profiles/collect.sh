@@ -1,11 +1,11 @@
 #!/bin/bash
 # Collect the judged artifact set on the GPU box (one gpurun call):
-#   bash profiles/collect.sh r3 [a|b]      (a: profiler passes + bench line, b: regime counters, timelines, regime table, CPU legs;
+#   bash profiles/collect.sh r4 [a|b]      (a: profiler passes + bench line, b: regime counters, timelines, regime table, CPU legs;
 #                                           nothing = both -- about 20 minutes, more than one gpurun call may take)
 # writes gpurun_out/<tag>_* and profiles/<tag>_{kernel_stats.csv,summary.json,summary.md}; the other files are copied
 # into profiles/ by hand afterwards (the raw kernel trace is large).
 set -o pipefail
-TAG=${1:-r3}
+TAG=${1:-r4}
 PART=${2:-ab}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out
@@ -17,9 +17,9 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_kt -o kt -- 
   > $OUT/${TAG}_bench_under_rocprofv3.json 2> $OUT/${TAG}_kt.err || exit 1
 echo "kernel trace done"
 # 3. HBM traffic: one counter per pass, nothing else enabled
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/${TAG}_pmc_fetch -o pf -- python3 $ROOT/bench.py --steps 5 --warmup 1 --no-cpu-baseline \
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/${TAG}_pmc_fetch -o pf -- python3 $ROOT/bench.py --steps 5 --warmup 1 --steady-steps 0 --order cold --no-cpu-baseline \
   > /dev/null 2> $OUT/${TAG}_pf.err || exit 1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/${TAG}_pmc_write -o pw -- python3 $ROOT/bench.py --steps 5 --warmup 1 --no-cpu-baseline \
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/${TAG}_pmc_write -o pw -- python3 $ROOT/bench.py --steps 5 --warmup 1 --steady-steps 0 --order cold --no-cpu-baseline \
   > /dev/null 2> $OUT/${TAG}_pw.err || exit 1
 echo "pmc passes done"
 cd $ROOT && python3 profiles/summarize.py $TAG $OUT/${TAG}_kt $OUT/${TAG}_pmc_fetch $OUT/${TAG}_pmc_write
@@ -27,9 +27,9 @@ cp "$(ls $OUT/${TAG}_kt/*/*_kernel_trace.csv $OUT/${TAG}_kt/*_kernel_trace.csv 2
 # 4. the other regimes under the same profiler: Infinity-Cache resident (12 envs) and the reference's small environments
 cd /tmp
 SUMMARY_WORKLOAD="bench.py --envs 12 (N=1e6, Ng=256, fp64: particles resident in the 256 MB Infinity Cache)" \
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_kt_env12 -o kt -- python3 $ROOT/bench.py --steps 100 --warmup 10 --envs 12 --no-cpu-baseline \
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_kt_env12 -o kt -- python3 $ROOT/bench.py --steps 100 --warmup 10 --envs 12 --steady-steps 200 --no-cpu-baseline \
   > $OUT/${TAG}_env12_under_rocprofv3.json 2> $OUT/${TAG}_kt_env12.err || exit 1
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_kt_small -o kt -- python3 $ROOT/bench.py --steps 200 --warmup 20 --envs 256 --particles 5000 --mesh 250 --no-cpu-baseline \
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_kt_small -o kt -- python3 $ROOT/bench.py --steps 200 --warmup 20 --envs 256 --particles 5000 --mesh 250 --steady-steps 400 --no-cpu-baseline \
   > $OUT/${TAG}_small256_under_rocprofv3.json 2> $OUT/${TAG}_kt_small.err || exit 1
 for d in env12 small; do cp "$(ls $OUT/${TAG}_kt_$d/*/*_kernel_stats.csv $OUT/${TAG}_kt_$d/*_kernel_stats.csv 2>/dev/null | head -1)" $OUT/${TAG}_kernel_stats_$d.csv; done
 echo "regime traces done"
@@ -37,9 +37,11 @@ cd $ROOT
 # 4b. resident schedule: VALU wave-instructions per particle-step (bench.py prices its roofline with them), float64 and fixed32
 cd /tmp
 for fmt in "float64 float" "float32 fixed32"; do set -- $fmt
-  rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES --output-format csv -d $OUT/${TAG}_pmc_res_$1 -o pr -- python3 $ROOT/bench.py --no-cpu-baseline \
-    --steady-steps 0 --profile-steps 0 --envs 256 --particles 5000 --mesh 250 --steps 100 --warmup 100 --dtype $1 --positions $2 > /dev/null 2> $OUT/${TAG}_pmc_res_$1.err \
-    && python3 $ROOT/profiles/resident_valu.py $TAG $OUT/${TAG}_pmc_res_$1 "$1/$2/N=5000/Ng=250" 5000 256 100
+  for hist in "" "--history"; do
+  rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES --output-format csv -d $OUT/${TAG}_pmc_res_$1$hist -o pr -- python3 $ROOT/bench.py --no-cpu-baseline \
+    --steady-steps 0 --profile-steps 0 --order cold --envs 256 --particles 5000 --mesh 250 --steps 100 --warmup 100 --dtype $1 --positions $2 $hist > /dev/null 2> $OUT/${TAG}_pmc_res_$1$hist.err \
+    && python3 $ROOT/profiles/resident_valu.py $TAG $OUT/${TAG}_pmc_res_$1$hist "$1/$2/N=5000/Ng=250${hist:+/history}" 5000 256 100
+  done
 done
 echo "resident pmc done"
 cd $ROOT

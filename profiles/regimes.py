@@ -13,7 +13,7 @@ CASES = [
     ("config 2: N=1e6, Ng=256, 64 envs, fp64", "--config 2 --steps 200 --warmup 20"),
     ("config 3 as specified: two-stream, N=1e6, Ng=512, 128 envs, fp32 + fixed-point positions, a new random action every step (one pic_step_actions_traj call)", "--config 3 --steps 50 --warmup 5"),
     ("config 3, one pic_step_actions call per step (a trainer's loop)", "--config 3 --steps 50 --warmup 5 --per-step-calls"),
-    ("config 3 with float32 positions", "--config 3 --positions float --steps 50 --warmup 5"),
+    ("config 3 in plain fp32 (float32 positions: BASELINE's wording; the preset above is the recommended float32 format)", "--config 3 --positions float --steps 50 --warmup 5"),
     ("config 3 shape without control (one pic_step call for all steps)", "--config 3 --actions 0 --steps 50 --warmup 5"),
     ("config 4 share: N=4e6, Ng=1024, 64 envs, fp64", "--config 4 --steps 20 --warmup 3 --steady-steps 50"),
     ("config 5 share: N=1e7, Ng=256, 128 envs, fp32 push / fp64 mesh", "--config 5 --steps 10 --warmup 2 --steady-steps 20"),
@@ -27,6 +27,10 @@ CASES = [
     ("reference shape x 64 (resident)", "--steps 500 --warmup 50 --envs 64 --particles 5000 --mesh 250"),
     ("reference shape x 256 (resident)", "--steps 500 --warmup 50 --envs 256 --particles 5000 --mesh 250"),
     ("reference shape x 1024 (resident)", "--steps 500 --warmup 50 --envs 1024 --particles 5000 --mesh 250"),
+    ("reference shape x 1, every step's refresh made and recorded (pic_step_history)", "--steps 500 --warmup 50 --envs 1 --particles 5000 --mesh 250 --history"),
+    ("reference shape x 64, every step's refresh made and recorded", "--steps 500 --warmup 50 --envs 64 --particles 5000 --mesh 250 --history"),
+    ("reference shape x 256, every step's refresh made and recorded", "--steps 500 --warmup 50 --envs 256 --particles 5000 --mesh 250 --history"),
+    ("reference shape x 1024, every step's refresh made and recorded", "--steps 500 --warmup 50 --envs 1024 --particles 5000 --mesh 250 --history"),
     ("reference shape x 256, a new action every step, one call (resident)", "--steps 500 --warmup 50 --envs 256 --particles 5000 --mesh 250 --actions 5"),
     ("reference shape x 256, one pic_step_actions call per step (resident)", "--steps 500 --warmup 50 --envs 256 --particles 5000 --mesh 250 --actions 5 --per-step-calls"),
     ("reference shape x 256, sweeps (--blocks-per-env 2)", "--steps 500 --warmup 50 --envs 256 --particles 5000 --mesh 250 --blocks-per-env 2"),
@@ -40,13 +44,16 @@ CASES = [
 def main():
     out = sys.argv[1]
     os.makedirs(out, exist_ok=True)
-    print("| workload | schedule | particle-steps/s | us/step | steady-state us/step | kernels (avg us per launch) | roofline of the dominant kernel | copy probe GB/s |")
-    print("|---|---|---|---|---|---|---|---|")
+    print("`refresh`: whether the post-step refresh of SURVEY 8d's step (density, E_mesh, phi, KE / PE: pic.py:145-146) is made after EVERY "
+          "step of a call or only after the last one (a plain pic_step(nsteps) call of the resident schedule skips the refreshes nothing "
+          "can observe; the streaming schedule, pic_step_history and one-step calls make them all).\n")
+    print("| workload | schedule | refresh | particle-steps/s | us/step | steady-state us/step | first steps of the handle, us/step | kernels (avg us per launch) | roofline of the dominant kernel | copy probe GB/s |")
+    print("|---|---|---|---|---|---|---|---|---|---|")
     for k, (name, args) in enumerate(CASES):
         r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline"] + args.split(), capture_output=True, text=True)
         lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
         if not lines:
-            print(f"| {name} | FAILED | | | | {r.stderr[-200:]!r} | | |")
+            print(f"| {name} | FAILED | | | | | | {r.stderr[-200:]!r} | | |")
             continue
         open(os.path.join(out, f"case{k:02d}.json"), "w").write(lines[-1] + "\n")
         d = json.loads(lines[-1])
@@ -61,8 +68,10 @@ def main():
         else:
             roof = "VALU issue + latency (no counter pass for this format)"
         ss = d.get("steady_state") or {}
-        print(f"| {name} | {d['config'].get('schedule', '')} | {d['value']:.3e} | {d['ms_per_step'] * 1e3:.1f} | "
-              f"{ss.get('ms_per_step', float('nan')) * 1e3:.1f} | {kern} | {roof} | {rf['measured_inplace_copy_GBs']:.0f} |", flush=True)
+        cs = d.get("cold_start") or {}
+        print(f"| {name} | {d['config'].get('schedule', '')} | {d['config'].get('refresh', '')} | {d['value']:.3e} | {d['ms_per_step'] * 1e3:.1f} | "
+              f"{ss.get('ms_per_step', float('nan')) * 1e3:.1f} | {cs.get('ms_per_step', float('nan')) * 1e3:.1f} | {kern} | {roof} | "
+              f"{rf['measured_inplace_copy_GBs']:.0f} |", flush=True)
 
 
 if __name__ == "__main__":

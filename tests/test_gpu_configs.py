@@ -159,7 +159,9 @@ def test_config4_share_bump_on_tail_4e6_1024_64envs_fp64(oc, po):
 
 def fp32_config(oc, po, tag, kind, E_, N, Ng, seed, with_actions, bounds, position_dtype=None):
     """fp32 particles against (i) the fp64 HIP path on every environment, same float32-representable start
-    and the same per-step actions, (ii) the oracle for environment 0 after one step."""
+    and the same per-step actions, (ii) the oracle for environment 0 after 1, 10 and 20 steps.  No reference fixture can
+    cover these modes (the reference is float64 only): beyond this, parity of the float32 formats is pinned through the
+    float64 path."""
     import torch
     L, n0, M = 50.0, 1.0, 3
     kw = {} if position_dtype is None else {"position_dtype": position_dtype}
@@ -185,20 +187,19 @@ def fp32_config(oc, po, tag, kind, E_, N, Ng, seed, with_actions, bounds, positi
         hi.set_actuator(act)
     ke0, pe0, _ = lo.energies()
     rng = np.random.default_rng(seed)
-    exts0 = []
+    # the oracle follows environment 0 through all 20 steps (round 4; rounds 2-3 compared after the first step only)
+    ref = po.OraclePIC(x0, v0, Ng, L=L, dt=0.1, perturb=False, faithful=False)
     checkpoints = {1, 10, 20}
     for k in range(1, 21):
         if with_actions:
             a = rng.uniform(-1.25, 1.25, (E_, 2 * M))             # a new action every step
             lo.step_actions(a)
             hi.step_actions(a)
-            if k == 1:
-                exts0.append(act.compute_E_batched(a)[0])
+            ref.update_state(act.compute_E_batched(a)[0].reshape(-1, 1))
         else:
             lo.step()
             hi.step()
-            if k == 1:
-                exts0.append(None)
+            ref.update_state(None)
         if k not in checkpoints:
             continue
         lo.sync(); hi.sync()
@@ -215,13 +216,14 @@ def fp32_config(oc, po, tag, kind, E_, N, Ng, seed, with_actions, bounds, positi
         for name, val in (("x", ex), ("v", ev), ("n", en), ("E_mesh", eE), ("KE", eke), ("PE", epe)):
             record_measure(f"{tag}.vs_fp64.step{k}.{name}", val)
             assert val < bounds[k][name], (k, name, val)
-        if k == 1:
-            ref = oracle_after(po, x0, v0, Ng, L, 0.1, exts0)
-            xo, vo = env_state(lo, 0)
-            eo = {"x": circ_err(xo, ref.x, L) / L, "v": rel_err(vo, ref.v), "E_mesh": rel_err(El[0], ref.E_mesh)}
-            for name, val in eo.items():
-                record_measure(f"{tag}.vs_oracle.step1.{name}", val)
-                assert val < bounds[1][name], (name, val)
+        # ... and environment 0 against the oracle (float64 NumPy restatement of the reference) at every checkpoint, at the
+        # bounds held against the float64 HIP run (which follows the oracle to 1e-13: the two errors are the same error)
+        xo, vo = env_state(lo, 0)
+        eo = {"x": circ_err(xo, ref.x, L) / L, "v": rel_err(vo, ref.v), "E_mesh": rel_err(El[0], ref.E_mesh),
+              "n": rel_err(nl[0], ref.n), "PE": abs(pl[0] / ref.get_electric_energy() - 1)}
+        for name, val in eo.items():
+            record_measure(f"{tag}.vs_oracle.step{k}.{name}", val)
+            assert val < bounds[k][name], (k, name, val)
     dxm = L / Ng
     n, _, _ = lo.fields()
     charge = float(np.max(np.abs(n.sum(axis=1) * dxm - n0 * L)))
