@@ -15,8 +15,8 @@ Rank 0 prints ONE JSON line (contract in DESIGN.md "Measurement").
 Order of the regions (profiles/experiments_r4.md 2): a device that has rested for >= 3 ms runs its next ~60 ms of
 sweeps 13 % -> 1 % slow, whatever ran on it before and whichever handle steps (the CPU leg in front of this script's GPU part
 is such a rest).  The default order therefore times the K headline steps LAST, behind the regions this script measures anyway:
-    cold_start (the first K steps of the handle, on the rested device: reported, round 3's headline) -> steady_state (>= 2 s of
-    steps) -> the event-bracketed pass (K steps, per-kernel durations for `roofline`) -> W warm-up steps -> K timed steps = `value`.
+    cold_start (the first K steps of the handle, on the rested device: reported, round 3's headline) -> the event-bracketed pass
+    (K steps, per-kernel durations for `roofline`) -> steady_state (~2 s of steps) -> W warm-up steps -> K timed steps = `value`.
 `--order cold` puts W + K first, as rounds 1-3 had it.  `value` is K steps behind W warm-up steps either way.
 """
 import argparse
@@ -184,7 +184,7 @@ def main():
                          "200 and 20000 steps: 1950 at config 2 -- long enough for an outside sampler such as rocm-smi to see the "
                          "device at work and for the figure to span the device's power management)")
     ap.add_argument("--order", default="warm", choices=["warm", "cold"],
-                    help="warm (default): cold_start, steady_state and the event-bracketed pass run BEFORE the W warm-up and K timed "
+                    help="warm (default): cold_start, the event-bracketed pass and steady_state run BEFORE the W warm-up and K timed "
                          "steps, so that the timed region sees the device in its working state; cold: W + K first (rounds 1-3), the "
                          "other regions behind them")
     ap.add_argument("--per-step-calls", action="store_true",
@@ -342,10 +342,10 @@ def main():
         # The regions this script measures anyway, in front of the headline one (module docstring): every rank runs them, so that
         # all devices of a multi-GPU run are in the same state when the timed region starts.
         cold = {"steps": args.steps, "ms_per_step": timed_region(args.steps)}
-        if args.steady_steps > 0:
-            steady = {"steps": args.steady_steps, "ms_per_step": timed_region(args.steady_steps)}
         if psteps > 0:
             prof, ms_per_step_events = event_pass()
+        if args.steady_steps > 0:        # last: nothing but the W warm-up steps and a barrier between its end and the timed region
+            steady = {"steps": args.steady_steps, "ms_per_step": timed_region(args.steady_steps)}
 
     run_steps(args.warmup)
     if args.order == "cold":
@@ -453,7 +453,7 @@ def main():
         "hbm_frac_of_step": value / world * MOVED_BYTES_PER_PARTICLE_STEP[args.dtype] / (HBM_PEAK_GBS * 1e9),
         "survey_112B_equivalent": value / world * ALGORITHMIC_BYTES_PER_PARTICLE_STEP[args.dtype] / (HBM_PEAK_GBS * 1e9),
         # the regions around the headline one, in the order they ran (module docstring); each on rank 0's own clock
-        "order": (["cold_start", "steady_state", "event_pass", "warmup", "timed"] if args.order == "warm"
+        "order": (["cold_start", "event_pass", "steady_state", "warmup", "timed"] if args.order == "warm"
                   else ["warmup", "timed", "steady_state", "event_pass"]),
         "cold_start": cold, "steady_state": steady,
         "per_rank_ms_per_step": per_rank_ms, "returns_all_gather_ms": gather_ms,

@@ -748,8 +748,13 @@ def test_phase_histogram_and_kl_on_device(oc):
 
 def test_edge_sizes(oc, po):
     """Ragged and extreme shapes: fewer particles than one tile, one particle, the largest mesh,
-    a mesh over the LDS limit, zero steps."""
+    a mesh over the LDS limit, zero steps.
+    Parity is checked only where the reference itself is defined: for some (L, Ng) pairs the Sherman-Morrison denominator of
+    its periodic solve (src/env/solve.py:27-53) is exactly 0 and its fields are inf / nan (the oracle, which restates
+    that solve, warns "divide by zero" here).  For those shapes the oracle branch below is SKIPPED -- parity is undefined there,
+    not green -- and only the size-independent properties (charge, no bad positions) are asserted; `skipped` names them."""
     L = 50.0
+    skipped = []
     for N, Ng in ((1, 8), (7, 16), (511, 64), (513, 64), (4097, 2700)):
         rng = np.random.default_rng(N)
         x0, v0 = rng.uniform(0, L, N), rng.normal(0, 1, N)
@@ -765,9 +770,13 @@ def test_edge_sizes(oc, po):
             x, v = env.particles()
             assert circ_err(x[0], ref.x, L) / L < 1e-12 and rel_err(v[0], ref.v) < 1e-11, (N, Ng)
             assert rel_err(env.fields()[1][0], ref.E_mesh) < 1e-9, (N, Ng)
+        else:
+            skipped.append((N, Ng))
         n = env.fields()[0]
         assert np.allclose(n.sum(axis=1) * (L / Ng), L, rtol=1e-12) and env.bad_count() == 0
         env.close()
+    assert len(skipped) < 5, skipped              # at least one of the shapes is compared with the oracle
+    print("test_edge_sizes: the reference's solve is singular, no parity asserted, for (N, Ng) in", skipped)
     with pytest.raises(oc._abi.PicError, match="Ng too large"):
         oc.BatchedPIC(1, 1000, 4096, L=L, dt=0.05)
 
