@@ -36,7 +36,7 @@ def circ_err(xa, xb, L):
     return float(np.max(np.minimum(d, L - d)))
 
 
-# Measured error margins of the GPU tests: every call appends "name: value" to gpurun_out/measured_r3.json on the
+# Measured error margins of the GPU tests: every call appends "name: value" to gpurun_out/measured_r4.json on the
 # box (gpurun merges that directory back), so that the asserted bounds can be quoted against what was measured.
 _MEASURED = {}
 
@@ -47,7 +47,7 @@ def record_measure(name, value):
     out = os.path.join(ROOT, "gpurun_out")
     try:
         os.makedirs(out, exist_ok=True)
-        with open(os.path.join(out, "measured_r3.json"), "w") as f:
+        with open(os.path.join(out, "measured_r4.json"), "w") as f:
             json.dump(_MEASURED, f, indent=1, sort_keys=True)
     except OSError:
         pass

@@ -218,9 +218,10 @@ def main():
 
 
 def composed_loops(only=()):
-    """G12-G14 (round 4): the reference's own LOOPS around the step, run as it writes them -- the closed feedback loop of
-    run_feedback.py:130-168, PIC.simulate (src/env/pic.py:175-223) and the behaviour-cloning rollout of
-    src/control/rl/ddpg.py:364-381 with its hard-coded spectrum arguments (n0 = 1, L = 50, Ng = 250)."""
+    """G12-G15 (round 4): the reference's own LOOPS around the step, run as it writes them -- the closed feedback loop of
+    run_feedback.py:130-168, PIC.simulate (src/env/pic.py:175-223), the behaviour-cloning rollout of
+    src/control/rl/ddpg.py:364-381 with its hard-coded spectrum arguments (n0 = 1, L = 50, Ng = 250), and
+    PIC.update_state_w_input_func (pic.py:148-163) with a pure function of the sub-stage state."""
     from src.env.pic import PIC
     from src.env.dist import BumpOnTail, TwoStream
     from src.control.actuator import E_field
@@ -312,10 +313,37 @@ def composed_loops(only=()):
                         f"{tag}_v_final": env.v.copy(), f"{tag}_E_mesh_final": env.E_mesh.copy(), f"{tag}_steps": K})
         save("g14_bc_rollout", **out)
 
+    # ---- G15: PIC.update_state_w_input_func (pic.py:148-163) with a PURE input function of the sub-stage state -----------------
+    if want("g15"):
+        N, Ng, K = 3000, 128, 5
+        np.random.seed(52)
+        sim = PIC(N=N, N_mesh=Ng, n0=1.0, L=L, dt=0.1, tmin=0.0, tmax=50.0, gamma=5.0, A=0.1, n_mode=2, interpol="CIC",
+                  init_dist=TwoStream(v0=3.0, sigma=1.0, n_samples=N, L=L))
+        mesh = np.linspace(0, L, Ng).reshape(-1, 1)
+        calls = []
+
+        def input_func(eta):
+            calls.append(eta.copy())                 # as handed over: before compute_E wraps eta[:N] in place (util.py:51)
+            a = np.mean(np.cos(2 * np.pi * eta[:N] / L))
+            b = np.mean(eta[N:] ** 2)
+            return 0.3 * a * np.sin(2 * np.pi * mesh / L) + 0.02 * b * np.cos(4 * np.pi * mesh / L)
+
+        out = dict(L=L, Ng=Ng, N=N, n0=1.0, dt=sim.dt, steps=K, x_init=sim.x.copy(), v_init=sim.v.copy())
+        xs, vs, Es, Hs, ncalls = [], [], [], [], []
+        for k in range(K):
+            calls.clear()
+            sim.update_state_w_input_func(input_func)
+            ncalls.append(len(calls))
+            if k == 0:      # the three calls whose force the integrator uses: [q1; p0], [q2; p1], [q3; p2] (calls 1, 3, 5 of 7)
+                out["useful_calls_step1"] = np.stack([calls[i][:, 0] for i in (1, 3, 5)])
+            xs.append(sim.x[:, 0].copy()); vs.append(sim.v[:, 0].copy()); Es.append(sim.E_mesh[:, 0].copy()); Hs.append(sim.get_energy())
+        out.update(x=np.array(xs), v=np.array(vs), E_mesh=np.array(Es), H=np.array(Hs), calls_per_step=np.array(ncalls))
+        save("g15_input_func", **out)
+
 
 if __name__ == "__main__":
-    # `make_golden.py g12 g13 g14` regenerates only the named composed-loop fixtures; no argument = everything
-    sel = tuple(a for a in sys.argv[1:] if a in ("g12", "g13", "g14"))
+    # `make_golden.py g12 g13 g14 g15` regenerates only the named composed-loop fixtures; no argument = everything
+    sel = tuple(a for a in sys.argv[1:] if a in ("g12", "g13", "g14", "g15"))
     if sel:
         _import_reference()
         composed_loops(sel)

@@ -1,9 +1,10 @@
 """The reference's own LOOPS around the step, against fixtures the reference itself produced (tests/golden/make_golden.py,
-composed_loops: G12-G14, round 4):
+composed_loops: G12-G15, round 4):
 
   G12  run_feedback.py:130-168        the closed feedback loop (two-stream, N = 5000, Ng = 250, max_mode = 5, 50 steps)
   G13  src/env/pic.py:175-223         PIC.simulate with and without a field trajectory
   G14  src/control/rl/ddpg.py:364-381 the behaviour-cloning rollout with its hard-coded spectrum arguments (n0 = 1, L = 50, Ng = 250)
+  G15  src/env/pic.py:148-163         update_state_w_input_func with a pure function of the sub-stage state
 
 Each loop is run (a) as the reference writes it, with this package's objects in the reference's places, and (b) through the one-call
 entry points that replace it on the device (pic_step_feedback, pic_step_ext_traj, pic_step_snapshots), on both schedules.  Bounds
@@ -262,3 +263,46 @@ def test_g14_bc_rollout_on_the_device(oc, bpe):
         record_measure(f"g14a.one_call.bpe{bpe}.{name}", val)
     assert e_act < 1e-9 and e_rew < 1e-9 and ex < TOL_X and ev < TOL_V and eE < TOL_E
     env.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# G15: PIC.update_state_w_input_func (pic.py:148-163) with a pure input function
+# ---------------------------------------------------------------------------------------------------------------------
+def test_g15_update_state_w_input_func(oc):
+    """The drop-in calls the input function 3 times per step where the reference calls it 7 times (first table):
+    for a PURE function of the sub-stage state the step is the reference's -- particles, field and energy of 5 steps against the
+    fixture, and the three states it hands to the function in step 1 are the reference's calls 1, 3 and 5 (the ones whose force
+    the integrator uses, src/env/integration.py:31-32)."""
+    g = load_golden("g15_input_func")
+    L, Ng, N, K = float(g["L"]), int(g["Ng"]), int(g["N"]), int(g["steps"])
+    np.random.seed(52)
+    sim = oc.PIC(N=N, N_mesh=Ng, n0=1.0, L=L, dt=0.1, tmin=0.0, tmax=50.0, gamma=5.0, A=0.1, n_mode=2, interpol="CIC",
+                 init_dist=oc.TwoStream(v0=3.0, sigma=1.0, n_samples=N, L=L))
+    assert np.array_equal(sim.x, g["x_init"]) and np.array_equal(sim.v, g["v_init"])
+    mesh = np.linspace(0, L, Ng).reshape(-1, 1)
+    calls = []
+
+    def input_func(eta):
+        calls.append(eta.copy())
+        a = np.mean(np.cos(2 * np.pi * eta[:N] / L))
+        b = np.mean(eta[N:] ** 2)
+        return 0.3 * a * np.sin(2 * np.pi * mesh / L) + 0.02 * b * np.cos(4 * np.pi * mesh / L)
+
+    worst = dict(x=0.0, v=0.0, E_mesh=0.0, H=0.0, calls=0.0)
+    for k in range(K):
+        calls.clear()
+        sim.update_state_w_input_func(input_func)
+        assert len(calls) == 3 and int(g["calls_per_step"][k]) == 7
+        if k == 0:
+            for mine, theirs in zip(calls, g["useful_calls_step1"]):
+                # sub-stage positions are unwrapped on both sides; compared on the circle in case a wrap differs by one box
+                worst["calls"] = max(worst["calls"], circ_err(np.mod(mine[:N, 0], L), np.mod(theirs[:N], L), L) / L,
+                                     rel_err(mine[N:, 0], theirs[N:]))
+        worst["x"] = max(worst["x"], circ_err(sim.x, g["x"][k], L) / L)
+        worst["v"] = max(worst["v"], rel_err(sim.v, g["v"][k]))
+        worst["E_mesh"] = max(worst["E_mesh"], rel_err(sim.E_mesh, g["E_mesh"][k]))
+        worst["H"] = max(worst["H"], abs(sim.get_energy() / g["H"][k] - 1))
+    for name, val in worst.items():
+        record_measure(f"g15.{name}", val)
+    assert worst["calls"] < 1e-13 and worst["x"] < TOL_X and worst["v"] < TOL_V and worst["E_mesh"] < TOL_E and worst["H"] < TOL_H
+    sim.close()

@@ -229,3 +229,33 @@ def test_g14_bc_rollout(tag):
         sim.update_state(po.actuator_field(L, Ng, 5, action[:5], action[5:]))
         assert abs(po.reward_value(state, action, Ng, L, 1.0, alpha=1.0, beta=0.5) - g[f"{tag}_reward"][k]) < 1e-9
     assert rel_err(sim.x, g[f"{tag}_x_final"]) < 1e-11 and rel_err(sim.E_mesh, g[f"{tag}_E_mesh_final"]) < 1e-9
+
+
+def test_g15_update_state_w_input_func():
+    """pic.py:148-163 with a pure input function: the oracle's Yoshida-4 composition (7 evaluations per step, as the reference
+    makes them) follows the reference for 5 steps, and its calls 1, 3, 5 of step 1 are the reference's."""
+    g = load_golden("g15_input_func")
+    L, Ng, N = float(g["L"]), int(g["Ng"]), int(g["N"])
+    mesh = np.linspace(0, L, Ng).reshape(-1, 1)
+    calls = []
+
+    def input_func(eta):
+        calls.append(eta.copy())
+        a = np.mean(np.cos(2 * np.pi * eta[:N] / L))
+        b = np.mean(eta[N:] ** 2)
+        return 0.3 * a * np.sin(2 * np.pi * mesh / L) + 0.02 * b * np.cos(4 * np.pi * mesh / L)
+
+    ref = po.OraclePIC(g["x_init"], g["v_init"], Ng, L=L, dt=float(g["dt"]), perturb=False, faithful=True)
+    for k in range(int(g["steps"])):
+        calls.clear()
+        eta = np.concatenate([ref.x.reshape(-1, 1), ref.v.reshape(-1, 1)], axis=0)
+        eta = po.yoshida4(eta, lambda z: ref.state_gradient(z, input_func(z)), ref.dt)
+        ref.x, ref.v = np.mod(eta[:N], L), eta[N:]
+        ref.update_density()
+        ref.update_E_field()
+        assert len(calls) == int(g["calls_per_step"][k]) == 7
+        if k == 0:
+            for i, c in zip((1, 3, 5), g["useful_calls_step1"]):
+                assert rel_err(calls[i][:, 0], c) < 1e-13
+        assert rel_err(ref.x[:, 0], g["x"][k]) < 1e-11 and rel_err(ref.v[:, 0], g["v"][k]) < 1e-11
+        assert rel_err(ref.E_mesh[:, 0], g["E_mesh"][k]) < 1e-9 and abs(ref.get_energy() / g["H"][k] - 1) < 1e-12
