@@ -42,7 +42,7 @@ enum { PIC_HOST = 0, PIC_DEVICE = 1 };       /* where a caller buffer lives     
 enum { PIC_PLACED_NONE = 0,                  /* pic_placement.outcome: no search (small state or PIC_PLACE_OFF)                    */
        PIC_PLACED_FOUND = 1,                 /* the pair kept streams >= 10 % faster than the slowest pair seen                    */
        PIC_PLACED_PATIENCE = 2,              /* 42 GiB walked without an improvement: all alike, the best of them kept             */
-       PIC_PLACED_TIMEOUT = 3,               /* 100 ms spent: the best pair seen so far kept                                       */
+       PIC_PLACED_TIMEOUT = 3,               /* the leg's 100 ms spent: the best pair seen so far kept; a reset may run another leg */
        PIC_PLACED_MEMORY = 4 };              /* a third of the free memory held (or an allocation failed): the best pair seen kept */
 
 enum {
@@ -275,9 +275,13 @@ int pic_schedule(pic_handle* h);
  * block for v) for a series of candidate blocks: on MI355X two arrays stream together at 6.05 TB/s when they lie in different
  * 32 GiB regions of HBM and at 5.25 TB/s when they share one.  The search stops sixteen readings after the best pair
  * seen is 10 % faster than the slowest seen (keeping the best of all), after 42 GiB walked without an improvement (more than a
- * 32 GiB region), after 100 ms, or when a third of the device's free memory is held -- whichever comes first; no absolute rate
- * enters.  Candidate blocks are allocated by a thread of the call's own while the calling thread times them (hipMalloc of memory
- * the device hands out for the first time costs 1.3 ms per 512 MB); it is joined before pic_create returns.
+ * 32 GiB region), or when a third of the device's free memory is held; no absolute rate enters.  It runs in LEGS of at most 100 ms:
+ * pic_create runs one; while the search has ended only for lack of time (outcome PIC_PLACED_TIMEOUT: on a device whose memory is
+ * handed out for the first time hipMalloc clears it at 1.3-6 ms per 512 MB block, and the first block that pairs well with x can be
+ * 31 GiB away), pic_reset / pic_reset_sampled -- which replace the particles anyway -- run another leg each, up to four in all, and
+ * may move v.  What an earlier leg has cleared and released comes back in microseconds, so every leg gets further.  Once
+ * pic_device_ptrs has handed out the addresses of x and v, v stays where it is and no further leg runs.  Candidate blocks are
+ * allocated by a thread of the call's own (joined before the call returns) while the calling thread times them.
  * What a co-resident allocator (torch's caching allocator, another handle on another thread or rank of the same device) sees:
  * while pic_create runs, blocks of the state's size are allocated one after the other and up to a third of the free memory is
  * held; all but x and v are freed before it returns.  An allocation made by someone else in that window can fail for lack of
@@ -288,18 +292,18 @@ int pic_schedule(pic_handle* h);
  * and of the slowest pair seen, in GB/s, and the wall time the search took; any pointer may be NULL. */
 int pic_placement_info(pic_handle* h, int* candidates, double* kept_gbytes_per_s, double* slowest_gbytes_per_s, double* seconds);
 
-/* The same report with how the search ended and where its time went (ABI 4).  malloc_seconds is the part a device that has just had
- * gigabytes released on it makes expensive (the driver wipes released memory before handing it out again: hipMalloc of a 512 MB
- * block takes 20-150 us on a quiet device and milliseconds there); timing_seconds the streaming passes (filler + one untimed + one
- * timed pass per pair); free_seconds the release of the blocks not kept. */
+/* The same report with how the search ended and where its time went, all legs together (ABI 4).  malloc_seconds is the part that
+ * memory handed out for the first time since the device came up makes expensive (the driver clears it inside hipMalloc: 1.3-6 ms per
+ * 512 MB block against 20-150 us for memory that has been allocated and released before); timing_seconds the streaming passes
+ * (filler, the leg's reference pair, one untimed + one timed pass per candidate); free_seconds the release of the blocks not kept. */
 typedef struct {
   int32_t pairs_timed;             /* 0: no search */
   int32_t blocks;                  /* candidate blocks allocated in all (timed or walked over) */
   int32_t outcome;                 /* PIC_PLACED_* */
-  int32_t reserved;
+  int32_t legs;                    /* legs of the search run so far: pic_create runs one, resets may run more (see above) */
   double kept_gbytes_per_s;        /* read + write rate of the bare stream over (x, v kept) */
   double slowest_gbytes_per_s;     /* ... over the slowest pair timed */
-  double seconds;                  /* wall time of the search inside pic_create */
+  double seconds;                  /* wall time of the search, all legs */
   double malloc_seconds, timing_seconds, free_seconds;
 } pic_placement;
 int pic_placement_stats(pic_handle* h, pic_placement* out);

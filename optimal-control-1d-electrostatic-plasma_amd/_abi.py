@@ -89,7 +89,7 @@ SIGNATURES = {
 
 
 class _Placement(C.Structure):
-    _fields_ = [("pairs_timed", C.c_int32), ("blocks", C.c_int32), ("outcome", C.c_int32), ("reserved", C.c_int32),
+    _fields_ = [("pairs_timed", C.c_int32), ("blocks", C.c_int32), ("outcome", C.c_int32), ("legs", C.c_int32),
                 ("kept_gbytes_per_s", C.c_double), ("slowest_gbytes_per_s", C.c_double), ("seconds", C.c_double),
                 ("malloc_seconds", C.c_double), ("timing_seconds", C.c_double), ("free_seconds", C.c_double)]
 
@@ -250,11 +250,11 @@ class Handle:
         return n.value, kept.value, slow.value, sec.value
 
     def placement_stats(self):
-        """pic_placement_stats as a dict: pairs_timed, blocks, outcome ("none" | "found" | "patience" | "timeout" | "memory"),
+        """pic_placement_stats as a dict: pairs_timed, blocks, legs, outcome ("none" | "found" | "patience" | "timeout" | "memory"),
         kept_GBs, slowest_GBs, seconds, malloc_seconds, timing_seconds, free_seconds."""
         st = _Placement()
         self._chk(self.lib.pic_placement_stats(self._h, C.byref(st)))
-        return {"pairs_timed": st.pairs_timed, "blocks": st.blocks,
+        return {"pairs_timed": st.pairs_timed, "blocks": st.blocks, "legs": st.legs,
                 "outcome": ("none", "found", "patience", "timeout", "memory")[st.outcome], "kept_GBs": st.kept_gbytes_per_s,
                 "slowest_GBs": st.slowest_gbytes_per_s, "seconds": st.seconds, "malloc_seconds": st.malloc_seconds,
                 "timing_seconds": st.timing_seconds, "free_seconds": st.free_seconds}

@@ -86,7 +86,12 @@ enum Stage : int {
   ST_C = 2,        // gather ; kick ; drift ; deposit ; store
   ST_D = 3,        // as C, then wrap, KE ; store wrapped x ; deposit the next step's q1 as well
   ST_REFRESH = 4,  // wrap x ; deposit ; KE ; store wrapped x ; deposit the next step's q1   (pic.py:93-112 on reset)
-  ST_PROBE = 5     // deposit positions of a scratch array, nothing stored             (util.py:73-116 callers)
+  ST_PROBE = 5,    // deposit positions of a scratch array, nothing stored             (util.py:73-116 callers)
+  // Inside a multi-step call (round 4): the post-step deposit of the final positions x' -- density, E_mesh, phi, PE of the state after
+  // a step, which nothing of the next step's dynamics reads -- moves from sweep D, the one sweep bound by VALU issue, into the next
+  // step's sweep B, which is bound by memory and reads x' anyway.  Same positions, same cells and weights, same integer sums.
+  ST_B2 = 6,       // as B, and deposits its INPUT positions (the previous step's x') into the second mesh
+  ST_D2 = 7        // as D without the deposit of x' (wrap, KE, store, the next step's q1 deposit)
 };
 
 // Mesh accumulators that cross a kernel boundary: per environment and node the sum of shape weights as a 64-bit
@@ -290,6 +295,31 @@ __device__ __forceinline__ T div_dx(T a, T dx, T rdx) {
   return fma(rem, rdx, q0);
 }
 
+// The part of `locate` behind the wrap: cell and weights of a position already in [0, L).  Sweep B2 uses it on the positions
+// sweep D2 stored (wrapped there): the same xw, hence the same cell and weights as the deposit D would have made.
+template <typename P, int SHAPE>
+__device__ __forceinline__ void locate_in_box(typename P::X xw, const Consts<P>& k, int& j, typename P::W (&w)[3], unsigned& frac) {
+  using T = typename P::W;
+  static_assert(!P::kFixed, "fixed-point positions need no wrap: locate() is the whole of it");
+  frac = 0u;
+  T jf = floor(div_dx(xw, k.dx, k.rdx));
+  j = (int)jf;
+  // j == Ng happens when xw/dx rounds up to Ng (undefined in the reference: bincount grows a bin and
+  // solve.py:32 raises); it is folded to node 0 with the weights of the unfolded index.
+  if ((unsigned)j >= (unsigned)k.Ng) j = 0;
+  if (SHAPE == PIC_CIC) {
+    w[0] = div_dx((jf + T(1)) * k.dx - xw, k.dx, k.rdx);
+    w[1] = div_dx(xw - jf * k.dx, k.dx, k.rdx);
+    w[2] = T(0);
+  } else {
+    T d = div_dx(xw - jf * k.dx, k.dx, k.rdx);
+    T a = T(1.5) - d, b = d - T(1), c = d - T(0.5);
+    w[0] = T(0.5) * (a * a);
+    w[1] = T(0.75) - b * b;
+    w[2] = T(0.5) * (c * c);
+  }
+}
+
 // Cell index and shape-function weights at position q.  j is the LDS index of the leftmost
 // touched node (mesh node + OFF, OFF = 1 for TSC so that node -1 has a slot).
 //   CIC (interpolate.py:6-13): jl = floor(xw/dx); wl = ((jl+1) dx - xw)/dx; wr = (xw - jl dx)/dx
@@ -316,24 +346,8 @@ __device__ __forceinline__ void locate(typename P::X q, const Consts<P>& k, type
       w[2] = T(0.5) * (c * c);
     }
   } else {
-    frac = 0u;
     xw = wrap_periodic(q, k.L, bad);
-    T jf = floor(div_dx(xw, k.dx, k.rdx));
-    j = (int)jf;
-    // j == Ng happens when xw/dx rounds up to Ng (undefined in the reference: bincount grows a bin and
-    // solve.py:32 raises); it is folded to node 0 with the weights of the unfolded index.
-    if ((unsigned)j >= (unsigned)k.Ng) j = 0;
-    if (SHAPE == PIC_CIC) {
-      w[0] = div_dx((jf + T(1)) * k.dx - xw, k.dx, k.rdx);
-      w[1] = div_dx(xw - jf * k.dx, k.dx, k.rdx);
-      w[2] = T(0);
-    } else {
-      T d = div_dx(xw - jf * k.dx, k.dx, k.rdx);
-      T a = T(1.5) - d, b = d - T(1), c = d - T(0.5);
-      w[0] = T(0.5) * (a * a);
-      w[1] = T(0.75) - b * b;
-      w[2] = T(0.5) * (c * c);
-    }
+    locate_in_box<P, SHAPE>(xw, k, j, w, frac);
   }
 }
 

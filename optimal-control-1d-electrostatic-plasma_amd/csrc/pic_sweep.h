@@ -63,18 +63,31 @@ __device__ __forceinline__ void push_one(typename P::X& xq, typename P::V& vp, c
   unsigned frac;
   typename P::X q = xq;
   typename P::V p = vp;
+  if (STAGE == ST_B2) {
+    // The post-step deposit of the PREVIOUS step (pic.py:145): q is the x' that step's sweep D2 wrapped and stored, so cell and
+    // weights are the ones its own deposit would have had (locate = wrap + locate_in_box, and the wrap of a wrapped position
+    // is the position).  A value outside [0, L) cannot come from D2; should memory hold one, its index folds to node 0 below.
+    if constexpr (P::kFixed) locate<P, SHAPE>(q, k, xw, j, w, frac, bad);
+    else locate_in_box<P, SHAPE>(q, k, j, w, frac);
+    deposit<A, P, SHAPE>(acc2, j, w, frac, k.magic);
+  }
   if (STAGE == ST_A) {
     q = drift<P>(q, p, k.c_cur, k, bad);                          // integration.py:42, c1
-  } else if (STAGE == ST_B || STAGE == ST_C || STAGE == ST_D) {
-    if (STAGE == ST_B) q = drift<P>(q, p, k.c_prev, k, bad);      // q1 again (it is never stored)
+  } else if (STAGE == ST_B || STAGE == ST_B2 || STAGE == ST_C || STAGE == ST_D || STAGE == ST_D2) {
+    if (STAGE == ST_B || STAGE == ST_B2) q = drift<P>(q, p, k.c_prev, k, bad);      // q1 again (it is never stored)
     locate<P, SHAPE>(q, k, xw, j, w, frac, bad);
     const T E = gather_field<T, SHAPE>(Es, j, w);                 // util.py:105 / pic.py:120
     p = p + (typename P::V)((k.d_cur * (-E)) * k.dt);             // integration.py:32, pic.py:127
     q = drift<P>(q, p, k.c_cur, k, bad);                          // integration.py:42
   }
-  locate<P, SHAPE>(q, k, xw, j, w, frac, bad);
-  deposit<A, P, SHAPE>(acc, j, w, frac, k.magic);
-  if (STAGE == ST_D || STAGE == ST_REFRESH) {
+  if (STAGE == ST_D2) {                                           // the wrap alone: the deposit of x' is the next sweep B2's
+    if constexpr (P::kFixed) xw = q;
+    else xw = wrap_periodic(q, k.L, bad);
+  } else {
+    locate<P, SHAPE>(q, k, xw, j, w, frac, bad);
+    deposit<A, P, SHAPE>(acc, j, w, frac, k.magic);
+  }
+  if (STAGE == ST_D || STAGE == ST_D2 || STAGE == ST_REFRESH) {
     q = xw;                                                       // pic.py:139 (+ util.py:51)
     ke += (double)p * (double)p;
     const typename P::X qn = drift<P>(q, p, k.c_next, k, bad);    // next step's q1 (integration.py:42, c1)
@@ -146,14 +159,15 @@ struct SweepIO {
   // coefficients (sweep D inside a rollout).  The sweeps that follow read it as a mesh field (host: run_stages).
   double* ext_out;
   const double* next_act;  // [env][2M] coefficients of the next step (environment 0), or null
-  acc_t* acc_out;          // receives this sweep's deposit (zero on entry)
-  acc_t* acc_out2;         // receives the next step's q1 deposit (dual stages)
+  acc_t* acc_out;          // receives this sweep's deposit (zero on entry; null in sweep D2, which makes none)
+  acc_t* acc_out2;         // receives the next step's q1 deposit (D, D2, REFRESH) / the previous step's final positions (B2)
   acc_t* zero0;            // accumulators no kernel reads any more: cleared for a later sweep
   acc_t* zero1;
   double* ke_part;         // [env][nblk] sum of p^2 per workgroup (dual stages)
   unsigned long long* bad; // [1] count of non-finite / unrepresentable positions
-  // Sweep B inside a multi-step pic_step call: the post-step refresh of the PREVIOUS step (pic.py:145-146) -- nothing this
-  // step reads -- is done by one extra workgroup per environment (blockIdx.x == nblk) instead of a launch of its own.
+  // Sweep C inside a multi-step pic_step call: the post-step refresh of the PREVIOUS step (pic.py:145-146) -- nothing this
+  // step reads -- is done by one extra workgroup per environment (blockIdx.x == nblk) instead of a launch of its own, from the
+  // deposit this step's sweep B2 made of the positions it read (rounds 2-3: sweep D deposited them and sweep B carried the solve).
   // post.acc == null: no such workgroup.
   SolveIO post;
 };
@@ -169,11 +183,14 @@ __global__ __launch_bounds__(BLOCK) void sweep_kernel(typename P::X* __restrict_
   using T = typename P::W;
   using XV = typename P::XV;
   using VV = typename P::VV;
-  constexpr bool kGather = (STAGE == ST_B || STAGE == ST_C || STAGE == ST_D);
-  constexpr bool kStore = (STAGE == ST_B || STAGE == ST_C || STAGE == ST_D || STAGE == ST_REFRESH);
-  constexpr bool kStoreV = (STAGE == ST_B || STAGE == ST_C || STAGE == ST_D);
+  constexpr bool kIsB = (STAGE == ST_B || STAGE == ST_B2), kIsD = (STAGE == ST_D || STAGE == ST_D2);
+  constexpr bool kGather = (kIsB || STAGE == ST_C || kIsD);
+  constexpr bool kStore = (kGather || STAGE == ST_REFRESH);
+  constexpr bool kStoreV = kGather;
   constexpr bool kReadV = (STAGE != ST_PROBE);
-  constexpr bool kDual = (STAGE == ST_D || STAGE == ST_REFRESH);
+  constexpr bool kFirst = (STAGE != ST_D2);                                    // deposits into the first LDS mesh (-> acc_out)
+  constexpr bool kDual = (kIsD || STAGE == ST_REFRESH || STAGE == ST_B2);      // ... into the second one (-> acc_out2)
+  constexpr bool kEnergy = (kIsD || STAGE == ST_REFRESH);                      // sum of p^2 per workgroup
 
   // LDS: [R meshes: acc][R meshes: acc2 (dual stages)][field tile Es]; the mesh region is the scratch of the
   // prologue solve first
@@ -188,7 +205,7 @@ __global__ __launch_bounds__(BLOCK) void sweep_kernel(typename P::X* __restrict_
   static_assert(sizeof(red) + sizeof(slot) == kSweepStaticLds, "pic_create adds the static LDS to the dynamic part it sizes");
   PIC_STAMP(0);
 
-  if (STAGE == ST_B && blockIdx.x == (unsigned)a.nblk) {      // the extra workgroup of its environment (host: only with io.post.acc)
+  if (STAGE == ST_C && blockIdx.x == (unsigned)a.nblk) {      // the extra workgroup of its environment (host: only with io.post.acc)
     // its arguments are read from the kernel-argument segment here, by this workgroup alone: held in scalar registers from the
     // kernel's entry on they cost every other workgroup of the sweep a wave of occupancy (pic_device.h: kernarg_at)
     SolveIO post = kernarg_at<SolveIO>(2 * sizeof(void*) + offsetof(SweepIO, post));   // x, v, io, a
@@ -242,7 +259,7 @@ __global__ __launch_bounds__(BLOCK) void sweep_kernel(typename P::X* __restrict_
                            (io.ext_out && blk == 0) ? io.ext_out + (size_t)env * Ng : nullptr, Ng, ldexp(1.0, -a.fg), a.scale, a.n0, a.dx,
                            reinterpret_cast<double*>(acc2_all), reinterpret_cast<double*>(smem_raw), slot, Es);
   }
-  if (STAGE == ST_D && io.next_act && io.ext_out && blk == 0) {   // (inside a rollout: one workgroup per environment)
+  if (kIsD && io.next_act && io.ext_out && blk == 0) {   // (inside a rollout: one workgroup per environment)
     const Control ctl = io.ctl;
     for (int j = tid; j < Ng; j += BLOCK)
       io.ext_out[(size_t)env * Ng + j] = actuator_field(ctl.basis, ctl.basis + (size_t)Ng * ctl.M, io.next_act + (size_t)env * 2 * ctl.M, j, ctl.M);
@@ -301,11 +318,11 @@ __global__ __launch_bounds__(BLOCK) void sweep_kernel(typename P::X* __restrict_
   PIC_STAMP(24);
 
   const size_t sub_row = (size_t)(blk % a.S) * a.sub + (size_t)env * Ng;
-  flush_mesh<A, SHAPE>(acc_all, a.R, stride, Ng, a.fg, io.acc_out + sub_row);
+  if (kFirst) flush_mesh<A, SHAPE>(acc_all, a.R, stride, Ng, a.fg, io.acc_out + sub_row);
   if (kDual) flush_mesh<A, SHAPE>(acc2_all, a.R, stride, Ng, a.fg, io.acc_out2 + sub_row);
   PIC_STAMP(25);
 
-  if (kDual) {
+  if (kEnergy) {
     double w = wave_sum(ke);
     if ((tid & 63) == 0) red[tid >> 6] = w;
     __syncthreads();

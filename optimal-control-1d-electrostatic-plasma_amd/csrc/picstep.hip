@@ -14,9 +14,10 @@
 //             deposit(next q1 = x' + (c1 p3) dt) into a second mesh
 //   solve   : n, E_mesh (no E_ext), phi, KE, PE, PE_reward        (pic.py:145-146, util.py:119-147)
 //
-// 4 launches and 3 read+write passes over the particles per step (96 B per particle-step in fp64); inside a multi-step
-// pic_step call the post-step solve of every step but the last rides with the next step's sweep B (one extra workgroup per
-// environment), so that a step there is 3 launches.  Every
+// 4 launches and 3 read+write passes over the particles per step (96 B per particle-step in fp64).  Inside a multi-step
+// pic_step call every step but the last ends with sweep D2 = D without deposit(x'); the next step's sweep B2 = B + deposit of the
+// positions it reads (that x') makes it instead -- D is the one sweep bound by VALU issue, B is bound by memory -- and the post-step
+// solve of the step rides with that step's sweep C (one extra workgroup per environment): 3 launches per step there.  Every
 // sweep workgroup solves the field it gathers from in its own prologue (pic_sweep.h: prologue_field), from
 // the accumulator row the previous sweep filled.
 //
@@ -65,6 +66,15 @@
 // ---------------------------------------------------------------------------------------------
 enum Format : int { FMT_F64 = 0, FMT_F32 = 1, FMT_U32 = 2 };     // PosF64 / PosF32 / PosU32
 typedef pic_placement PlacementStats;
+struct PlacementState {
+  size_t pbytes = 0;                  // size of x and of v (0: no search on this handle)
+  int legs = 0;                       // legs run so far
+  size_t frontier = 0;                // blocks the longest leg has walked over: a later leg takes no readings before that
+  double best_n = 0.0, worst_n = 0.0; // normalised readings of the block kept and of the slowest pair seen (0: none yet)
+  bool found = false;
+  bool ptrs_exposed = false;          // pic_device_ptrs has handed out the addresses of x and v: v stays where it is
+  bool x_cleared = false;
+};
 constexpr int RING = 8;                                          // accumulator rows in rotation
 
 struct pic_handle {
@@ -91,10 +101,12 @@ struct pic_handle {
   hipStream_t stream = nullptr;       // the stream every call works on (own_stream, or the caller's)
   hipStream_t own_stream = nullptr;   // created by pic_create, destroyed by pic_destroy
   bool v_separate = false;            // v is an allocation of its own (large states: alloc_particles)
-  int post_slot = -1;                 // ring row whose post-step solve rides with the next sweep B (inside pic_step only)
+  int post_slot = -1;                 // ring row whose post-step solve rides with the next sweep C (inside pic_step only)
+  bool refresh_pending = false;       // the last sweep was a D2 (inside pic_step only): the next sweep B deposits the positions it reads
   double* hist_row = nullptr;         // where the NEXT post-step solve also records its three energies (step_recording), or null
   double* post_hist_row = nullptr;    // the same for the solve that post_slot stands for
-  PlacementStats place{};             // what alloc_particles' search for an (x, v) placement did (pic_placement_stats)
+  PlacementStats place{};             // what the search for an (x, v) placement did, all legs together (pic_placement_stats)
+  PlacementState place_state{};       // what a later leg of it needs to know (placement_leg, resume_placement)
   void* x = nullptr;
   void* v = nullptr;
   void* scratch = nullptr;        // [env][ld] positions of a probe (eval_field / compute_E)
@@ -220,7 +232,7 @@ void ring_retire(pic_handle* h, int slot) {
 
 template <typename P, typename A, int SHAPE, int STAGE>
 void launch_sweep_t(pic_handle* h, const SweepIO& io, void* x, void* v, const SweepArgs& a) {
-  dim3 grid(h->nblk + ((STAGE == ST_B && io.post.acc) ? 1 : 0), h->cfg.num_envs);
+  dim3 grid(h->nblk + ((STAGE == ST_C && io.post.acc) ? 1 : 0), h->cfg.num_envs);
   static const InlineDoubles none{};
   hipLaunchKernelGGL((sweep_kernel<P, A, SHAPE, STAGE>), grid, dim3(BLOCK), h->sweep_lds, h->stream,
                      static_cast<typename P::X*>(x), static_cast<typename P::V*>(v), io, a, a.act_inline ? *h->inline_act : none);
@@ -234,6 +246,8 @@ void launch_sweep_s(pic_handle* h, const SweepIO& io, int stage, void* x, void* 
     case ST_C: launch_sweep_t<P, A, SHAPE, ST_C>(h, io, x, v, a); break;
     case ST_D: launch_sweep_t<P, A, SHAPE, ST_D>(h, io, x, v, a); break;
     case ST_REFRESH: launch_sweep_t<P, A, SHAPE, ST_REFRESH>(h, io, x, v, a); break;
+    case ST_B2: launch_sweep_t<P, A, SHAPE, ST_B2>(h, io, x, v, a); break;
+    case ST_D2: launch_sweep_t<P, A, SHAPE, ST_D2>(h, io, x, v, a); break;
     default: launch_sweep_t<P, A, SHAPE, ST_PROBE>(h, io, x, v, a); break;
   }
 }
@@ -296,7 +310,8 @@ void launch_sweep(pic_handle* h, int stage, void* x, void* v, double c_prev, dou
   SweepArgs a;
   a.N = h->cfg.N; a.ld = h->ld; a.chunk = h->chunk; a.Ng = h->cfg.Ng; a.nblk = h->nblk; a.R = h->R;
   a.act_inline = (ctl.act && h->inline_act) ? 1 : 0;
-  a.reverse = (stage <= ST_D) ? (h->sweep_parity ^= 1) : 0;
+  const bool push = stage <= ST_D || stage == ST_B2 || stage == ST_D2;
+  a.reverse = push ? (h->sweep_parity ^= 1) : 0;
   a.fg = h->fg; a.magic = h->magic;
   a.S = h->S; a.sub = (long long)h->cfg.num_envs * h->cfg.Ng;
   a.L = h->cfg.L; a.dx = h->dx; a.dt = h->cfg.dt;
@@ -321,13 +336,13 @@ void launch_sweep(pic_handle* h, int stage, void* x, void* v, double c_prev, dou
   io.zero1 = z[1] >= 0 ? ring_row(h, z[1]) : nullptr;
   io.ke_part = h->ke_part;
   io.bad = h->bad;
-  if (post_slot >= 0) {            // sweep B also carries the previous step's post-step refresh (pic_sweep.h: SweepIO::post)
+  if (post_slot >= 0) {            // sweep C also carries the previous step's post-step refresh (pic_sweep.h: SweepIO::post)
     io.post.acc = ring_row(h, post_slot);
     io.post.ke_part = h->ke_part; io.post.n = h->n; io.post.out.E = h->E_mesh; io.post.out.phi = h->phi;
     io.post.out.KE = h->KE; io.post.out.PE = h->PE; io.post.out.PEr = h->PEr;
     io.post.out.hist = h->post_hist_row; io.post.out.num_envs = h->cfg.num_envs;
   }
-  prof_begin(h, stage <= ST_D ? stage : 5);
+  prof_begin(h, stage <= ST_D ? stage : (stage == ST_B2 ? (int)ST_B : (stage == ST_D2 ? (int)ST_D : 5)));
   if (h->fmt == FMT_F64) launch_sweep_p<PosF64>(h, io, stage, x, v, a);
   else if (h->fmt == FMT_F32) launch_sweep_p<PosF32>(h, io, stage, x, v, a);
   else launch_sweep_p<PosU32>(h, io, stage, x, v, a);
@@ -566,59 +581,64 @@ const char* pic_last_error(pic_handle* h) { return h ? h->err.c_str() : g_create
 // pages from several regions (profiles/touch_probe.hip, experiments_r4.md 1: the class of a 64 MB window follows the window of x
 // it is paired with, not the candidate), which is why the search times WHOLE blocks, never windows of them.
 // For particle states that live in HBM (>= 256 MB) x and v are therefore two allocations: x first, then blocks of the same
-// size one after the other (they are laid down in sequence), and the pair (x, newest block) is timed with a streaming pass again
-// and again while the blocks keep coming.  The search is a policy on RATIOS, not on this part's numbers: it ends sixteen readings
-// after the best pair seen streams >= 10 % faster than the slowest one seen (the kinds have been told apart and we hold a fast one), after
-// 42 GiB walked without an improvement (more than a region, all pairs alike: nothing to gain on this device), after 100 ms, or
-// when a third of the free memory is held; everything but x and v is freed before pic_create returns.
+// size one after the other (they are laid down in sequence), and every 3 GiB the pair (x, newest block) is timed with a streaming
+// pass.  The search is a policy on RATIOS, not on this part's numbers: it ends sixteen readings after the best pair seen streams
+// >= 10 % faster than the slowest one seen (the kinds have been told apart and we hold a fast one; the best of all is kept), after
+// 42 GiB walked without an improvement (more than a region, all pairs alike: nothing to gain on this device), or when a third of
+// the free memory is held; everything but x and v is freed before the call returns.
 // pic_config.placement = PIC_PLACE_OFF skips it (x | v in one block).  Smaller states keep x | v in one block too (they sit in
 // the Infinity Cache, and the one-copy read-back of pic_get_particles wants them adjacent).
 //
-// Where the time goes (round 4, profiles/experiments_r4.md 1).  Nothing is paid for the first touch of a block (touch_probe: first
-// pass 330 us, later ones 347), so a candidate is not cleared here and a reading is ONE pass behind one untimed pass.  What costs
-// is hipMalloc on a device nobody has used yet: the driver clears memory it hands out for the first time, 1.3 ms per 512 MB block
-// (released memory is cleared in the background and comes back in 20-70 us), and a first create on a fresh box has x at the very
-// start of a region -- 31 GiB = 80 ms of allocations away from the first block that pairs well with it.  So the blocks are
-// allocated by a thread of their own, at most kLead ahead of the one being timed, while this thread does nothing but time: the
-// walk advances at the allocator's speed, the stream never rests (a device that has rested >= 3 ms runs its next 10-20 ms 4-13 %
-// slow -- early_steps3.py -- and a search whose readings straddle that ramp sees a "10 % faster" pair of the SAME kind; ~10 ms of
-// filler passes over x absorb the ramp of the rested device a create starts on).
-struct BlockFeed {                                  // candidate blocks, allocated by a thread of their own (alloc_particles)
+// Where the time goes, and why the search comes in LEGS of at most 100 ms (round 4, profiles/experiments_r4.md 1).
+// * Nothing is paid for the first touch of a block (touch_probe: first pass 330 us, later ones 347): a candidate is not cleared
+//   here, a reading is one timed pass behind one untimed pass.
+// * What costs is hipMalloc of memory the device hands out for the first time since it came up: the driver clears it, 1.3 ms per
+//   512 MB block with the GPU otherwise idle and 3-6 ms under a streaming kernel (released memory is wiped in the background and
+//   comes back in 20-70 us).  A first create on such a device has x at the very start of a region, 31 GiB -- 80 to 200 ms of
+//   allocations -- from the first block that pairs well with it.  No budget that a constructor may take covers that.  But what one
+//   leg has cleared and given back stays clean, so the NEXT leg walks through it in microseconds per block and spends its 100 ms
+//   beyond: pic_create runs the first leg, and while it ends for lack of time pic_reset / pic_reset_sampled -- which replace the
+//   particles anyway, so that moving v costs nothing -- run further ones (at most kMaxLegs, and only as long as pic_device_ptrs has
+//   not handed the addresses to anybody).
+// * The blocks are allocated by a thread of the call's own while the calling thread times; over never-used memory (slow mallocs) the
+//   two take turns instead, because the clear and the timed stream slow each other down.
+// * A device that has rested >= 3 ms runs its next 10-20 ms 4-13 % slow (early_steps3.py), and readings taken at different points
+//   of that ramp show a "10 % faster" pair of the SAME kind.  Every reading is therefore a RATIO: the time of (x, candidate) over
+//   the time of (x, the leg's first block) taken in the same breath (again whenever the stream has rested since), behind a filler.
+struct BlockFeed {                                  // candidate blocks, allocated by a thread of their own (placement_leg)
   std::mutex m;
   std::condition_variable cv;
   std::vector<void*> blocks;                        // in allocation order; only ever grown by the feeder
   size_t taken = 0;                                 // blocks.size() when the timing thread last took one
   size_t lead = 1;                                  // the feeder stays at most this many blocks ahead of `taken`
   bool stop = false, done = false;
+  bool timing = false;                              // a reading is being taken
+  bool slow = false;                                // the last hipMalloc was of never-used memory (being cleared): take turns with the readings
   double malloc_seconds = 0.0;
 };
 
-hipError_t alloc_particles(pic_handle* h, size_t pbytes) {
-  constexpr size_t kMinBytes = (size_t)256 << 20;
+constexpr int kMaxLegs = 4;
+
+// One leg of the search.  On entry h->x is allocated; h->v is the block kept so far, or null (first leg).
+void placement_leg(pic_handle* h, size_t pbytes) {
   // Everything the search allocates has to be given back, and the driver wipes released memory before it hands it out again
   // (asynchronously; whatever allocates next on the device may wait for that): an untouched 32 GiB spacer that carried the search out
   // of x's own region at once made the next pic_create of a create / destroy loop take 0.4-3 s (experiments_r3.md 18).  Blocks of
   // the state's own size, given back within the call, do not.
-  constexpr size_t kLead = (size_t)3 << 30;         // the feeder stays at most this far ahead of the block being timed
-  constexpr double kGain = 1.10;                    // best / slowest rate at which the search has found what it looks for
+  constexpr size_t kLead = (size_t)3 << 30;         // distance between two readings
+  constexpr double kGain = 1.10;                    // slowest / best (normalised) at which the search has found what it looks for
   constexpr size_t kPatience = (size_t)42 << 30;    // walked without an improvement before giving up: more than the 32 GiB a region
                                                     // spans (15 GiB gave up inside x's own region on some boxes: 1049 instead of 958 us)
-  constexpr int kMore = 16;                         // pairs timed beyond the first that passes kGain
-  constexpr double kMaxSeconds = 0.100;
-  constexpr double kFreeSeconds = 0.0002;           // what giving one block back costs (hipFree: 25 ms for 110 blocks), inside the 100 ms
+  constexpr int kMore = 16;                         // readings beyond the first that passes kGain
+  constexpr double kMaxSeconds = 0.100;             // per leg, the release of the blocks included
+  constexpr double kFreeSeconds = 0.0002;           // what giving one block back costs (hipFree: 25 ms for 110 blocks)
+  constexpr double kSlowPerGiB = 0.0008;            // a hipMalloc slower than this per GiB is clearing never-used memory
   constexpr int kMaxBlocks = 192;
   PlacementStats& st = h->place;
-  st = PlacementStats{};
-  if (2 * pbytes < kMinBytes || h->cfg.placement == PIC_PLACE_OFF) {
-    const hipError_t e = hipMalloc(&h->x, 2 * pbytes);
-    h->v = static_cast<char*>(h->x) + pbytes;
-    return e;
-  }
+  PlacementState& ps = h->place_state;
   const auto t_begin = std::chrono::steady_clock::now();
   auto seconds = [t_begin]() { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count(); };
-  hipError_t e = hipMalloc(&h->x, pbytes);
-  if (e != hipSuccess) return e;
-  h->v_separate = true;
+  ps.legs += 1;
   size_t free_b = 0, total_b = 0;
   hipEvent_t e0 = nullptr, e1 = nullptr;
   bool ok = hipMemGetInfo(&free_b, &total_b) == hipSuccess && hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess;
@@ -636,16 +656,13 @@ hipError_t alloc_particles(pic_handle* h, size_t pbytes) {
   };
   const double pass_ms_guess = 2.0 * (double)pbytes / 5.0e9;           // one filler pass moves 2 x pbytes at ~5 TB/s
   const int fill_1ms = std::max(1, (int)std::ceil(1.0 / pass_ms_guess));
-  auto pair_ms = [&](void* vb, float* ms) {                            // one untimed pass over (x, candidate), one timed
+  auto pair_ms = [&](void* vb, float* ms) {                            // one untimed pass over (x, block), one timed
     double2* b = static_cast<double2*>(vb);
-    const double t0 = seconds();
     hipLaunchKernelGGL(stream_probe_kernel, dim3((unsigned)nb), dim3(BLOCK), 0, h->stream, xa, b, n2, chunk2, 1.0, 0);
     bool good = hipGetLastError() == hipSuccess && hipEventRecord(e0, h->stream) == hipSuccess;
     hipLaunchKernelGGL(stream_probe_kernel, dim3((unsigned)nb), dim3(BLOCK), 0, h->stream, xa, b, n2, chunk2, 1.0, 0);
-    good = good && hipGetLastError() == hipSuccess && hipEventRecord(e1, h->stream) == hipSuccess &&
+    return good && hipGetLastError() == hipSuccess && hipEventRecord(e1, h->stream) == hipSuccess &&
            hipEventSynchronize(e1) == hipSuccess && hipEventElapsedTime(ms, e0, e1) == hipSuccess;
-    st.timing_seconds += seconds() - t0;
-    return good;
   };
   const double gb_per_ms = 4.0 * (double)pbytes / 1e6;                // one pass, 2 arrays read and written: GB/s = this / ms
 
@@ -653,16 +670,19 @@ hipError_t alloc_particles(pic_handle* h, size_t pbytes) {
   const size_t lead_blocks = std::max<size_t>(1, kLead / pbytes);
   const int device = h->cfg.device_id;
   std::thread feeder;
-  if (ok) ok = hipMemsetAsync(h->x, 0, pbytes, h->stream) == hipSuccess;
+  if (ok && !ps.x_cleared) {
+    ok = hipMemsetAsync(h->x, 0, pbytes, h->stream) == hipSuccess;    // (x holds particles in a later leg: the passes scale by 1.0)
+    ps.x_cleared = true;
+  }
   if (ok) {
-    filler(10 * fill_1ms);                                            // the ramp of a rested device, run under the first allocations
     feed.lead = lead_blocks;
+    try {
     feeder = std::thread([&feed, seconds, pbytes, budget, device]() {
       const bool dev_ok = hipSetDevice(device) == hipSuccess;
       for (;;) {
         {
           std::unique_lock<std::mutex> lk(feed.m);
-          feed.cv.wait(lk, [&] { return feed.stop || feed.blocks.size() < feed.taken + feed.lead; });
+          feed.cv.wait(lk, [&] { return feed.stop || (feed.blocks.size() < feed.taken + feed.lead && !(feed.slow && feed.timing)); });
           if (feed.stop || !dev_ok || (int)feed.blocks.size() >= kMaxBlocks || (feed.blocks.size() + 2) * pbytes > budget ||
               seconds() + kFreeSeconds * (double)feed.blocks.size() > kMaxSeconds)
             break;
@@ -673,6 +693,7 @@ hipError_t alloc_particles(pic_handle* h, size_t pbytes) {
         const double dt = seconds() - tm;
         std::lock_guard<std::mutex> lk(feed.m);
         feed.malloc_seconds += dt;
+        feed.slow = dt > kSlowPerGiB * ((double)pbytes / (double)(1ull << 30));
         if (!got) { (void)hipGetLastError(); break; }
         feed.blocks.push_back(b);
         feed.cv.notify_all();
@@ -681,43 +702,88 @@ hipError_t alloc_particles(pic_handle* h, size_t pbytes) {
       feed.done = true;
       feed.cv.notify_all();
     });
+    } catch (...) {                                                   // no thread to be had: no search
+      ok = false;
+    }
   }
-  void* best = nullptr;
-  float best_ms = 0.f, worst_ms = 0.f;
+  // normalised readings: time of (x, block) / time of (x, the leg's first block) taken in the same breath
+  void* ref = nullptr;
+  float ref_ms = 0.f;
+  double last_reading_at = -1.0;                                      // seconds() when the stream last finished a reading
+  auto reading = [&](void* b, double* norm, float* raw_ms) {
+    const double t0 = seconds();
+    {
+      std::lock_guard<std::mutex> lk(feed.m);
+      feed.timing = true;
+    }
+    bool good = true;
+    const bool rested = last_reading_at < 0.0 || t0 - last_reading_at > 0.0005;
+    if (rested) {                                                     // the reference again, behind a filler: same point of the ramp
+      filler(last_reading_at < 0.0 ? 4 * fill_1ms : fill_1ms);
+      good = pair_ms(ref, &ref_ms);
+    }
+    if (good && b != ref) good = pair_ms(b, raw_ms); else *raw_ms = ref_ms;
+    last_reading_at = seconds();
+    {
+      std::lock_guard<std::mutex> lk(feed.m);
+      feed.timing = false;
+      feed.cv.notify_all();
+    }
+    *norm = (double)*raw_ms / (double)ref_ms;
+    st.timing_seconds += seconds() - t0;
+    return good;
+  };
+  void* best = h->v;                                                  // the block kept by earlier legs, or null
+  double best_n = ps.best_n, worst_n = ps.worst_n;                    // normalised; 0 = none yet
+  float best_raw = 0.f, worst_raw = 0.f;
   int timed = 0, found_at = 0;
   size_t last = 0, best_at = 0;                                       // blocks.size() at the last / at the best reading
-  st.outcome = PIC_PLACED_MEMORY;                                     // (the feeder ran into the block or memory limit, or hipMalloc failed)
+  int outcome = PIC_PLACED_MEMORY;                                    // (the feeder ran into the block or memory limit, or hipMalloc failed)
   while (ok) {
     void* b = nullptr;
     {
       std::unique_lock<std::mutex> lk(feed.m);
-      feed.cv.wait(lk, [&] { return feed.done || feed.blocks.size() > last; });
+      // the next reading is due `lead` blocks further on (or on what the feeder managed before it stopped)
+      feed.cv.wait(lk, [&] { return feed.done || feed.blocks.size() >= last + feed.lead; });
       if (feed.blocks.size() == last) break;                          // the feeder has stopped and every block it made has been looked at
-      last = feed.taken = feed.blocks.size();                         // the NEWEST block: the walk moves at the allocator's speed
+      last = feed.taken = feed.blocks.size();
       b = feed.blocks.back();
       if (found_at > 0) feed.lead = 1;                                // (past the first find every block is looked at: fewer to give back)
+      if (!ref) ref = feed.blocks.front();
       feed.cv.notify_all();
     }
-    if (seconds() + kFreeSeconds * (double)last > kMaxSeconds) {       // (the 100 ms include giving the blocks back)
-      if (st.outcome != PIC_PLACED_FOUND) st.outcome = PIC_PLACED_TIMEOUT;
+    if (seconds() + kFreeSeconds * (double)last > kMaxSeconds) {      // (the 100 ms include giving the blocks back)
+      outcome = PIC_PLACED_TIMEOUT;
       break;
     }
-    float ms = 0.f;
-    ok = pair_ms(b, &ms);
+    if (last <= ps.frontier) continue;                                // an earlier leg has been here: nothing new to learn
+    double n = 0.0;
+    float raw = 0.f;
+    if (timed == 0) {
+      // first reading of a leg: the reference itself (first leg: it is a candidate like any other, n = 1), or where the block
+      // kept by the earlier legs stands today
+      void* first = h->v ? h->v : ref;
+      ok = reading(first, &n, &raw);
+      if (!ok) break;
+      best = first; best_n = n; best_raw = raw; best_at = last;
+      if (worst_n < n) { worst_n = n; worst_raw = raw; }
+      ++timed;
+      if (b == first) continue;
+    }
+    ok = reading(b, &n, &raw);
     if (!ok) break;
     ++timed;
-    if (!best || ms < best_ms) { best = b; best_ms = ms; best_at = last; }
-    if (ms > worst_ms) worst_ms = ms;
-    if (worst_ms >= kGain * best_ms) {                                // a fast pair, known to be one ...
-      st.outcome = PIC_PLACED_FOUND;
+    if (best_n == 0.0 || n < best_n) { best = b; best_n = n; best_raw = raw; best_at = last; }
+    if (n > worst_n) { worst_n = n; worst_raw = raw; }
+    if (worst_n >= kGain * best_n) {                                  // a fast pair, known to be one ...
       // ... but there are more than two kinds (5.0-5.3 / 5.6-5.75 / 5.85-6.0 TB/s read on used devices, 0.983 / 0.970 / 0.963 ms per
       // step at config 2), and the first pair 10 % above the slowest is often of the middle one: a reading costs 0.7 ms, so
       // kMore further blocks are looked at and the best of all is kept
       if (found_at == 0) found_at = timed;
-      if (timed - found_at >= kMore) break;
+      if (timed - found_at >= kMore) { outcome = PIC_PLACED_FOUND; break; }
       continue;
     }
-    if ((last - best_at) * pbytes >= kPatience) { st.outcome = PIC_PLACED_PATIENCE; break; }
+    if ((last - best_at) * pbytes >= kPatience) { outcome = PIC_PLACED_PATIENCE; break; }
   }
   if (feeder.joinable()) {
     {
@@ -727,35 +793,60 @@ hipError_t alloc_particles(pic_handle* h, size_t pbytes) {
     }
     feeder.join();
   }
-  if (st.outcome == PIC_PLACED_MEMORY && seconds() + kFreeSeconds * (double)feed.blocks.size() > kMaxSeconds)
-    st.outcome = PIC_PLACED_TIMEOUT;                                  // (the feeder's own clock check)
+  if (outcome == PIC_PLACED_MEMORY && seconds() + kFreeSeconds * (double)feed.blocks.size() > kMaxSeconds)
+    outcome = PIC_PLACED_TIMEOUT;                                     // (the feeder's own clock check)
+  if (found_at > 0 && outcome == PIC_PLACED_TIMEOUT) outcome = PIC_PLACED_FOUND;      // a fast pair is in hand: no further leg for the rest of the sixteen
   (void)hipStreamSynchronize(h->stream);
   if (e0) hipEventDestroy(e0);
   if (e1) hipEventDestroy(e1);
   (void)hipGetLastError();
   std::vector<void*>& blocks = feed.blocks;
-  if (!best) {                                                        // nothing could be timed: any block will do
-    if (blocks.empty()) {
-      e = hipMalloc(&best, pbytes);
-      if (e != hipSuccess) return e;
-    } else {
-      best = blocks.front();
-    }
-  }
+  if (!best && !blocks.empty()) best = blocks.front();                // nothing could be timed: any block will do
   const double tf = seconds();
   for (void* b : blocks)
     if (b != best) hipFree(b);
-  st.free_seconds = seconds() - tf;
+  if (h->v && best != h->v) hipFree(h->v);                            // a later leg found a better block than the one kept
+  st.free_seconds += seconds() - tf;
   h->v = best;
-  st.blocks = (int)blocks.size();
-  st.pairs_timed = timed;
-  st.malloc_seconds = feed.malloc_seconds;
-  if (timed > 0) {
-    st.kept_gbytes_per_s = gb_per_ms / best_ms;
-    st.slowest_gbytes_per_s = gb_per_ms / worst_ms;
+  ps.best_n = best_n; ps.worst_n = worst_n;
+  ps.found = found_at > 0;
+  ps.frontier = std::max(ps.frontier, blocks.size());
+  st.blocks += (int)blocks.size();
+  st.pairs_timed += timed;
+  st.malloc_seconds += feed.malloc_seconds;
+  st.outcome = outcome;
+  if (best_raw > 0.f) st.kept_gbytes_per_s = gb_per_ms / best_raw;
+  if (worst_raw > 0.f && (st.slowest_gbytes_per_s == 0.0 || gb_per_ms / worst_raw < st.slowest_gbytes_per_s))
+    st.slowest_gbytes_per_s = gb_per_ms / worst_raw;
+  st.seconds += seconds();
+  st.legs = ps.legs;
+}
+
+hipError_t alloc_particles(pic_handle* h, size_t pbytes) {
+  constexpr size_t kMinBytes = (size_t)256 << 20;
+  h->place = PlacementStats{};
+  h->place_state = PlacementState{};
+  if (2 * pbytes < kMinBytes || h->cfg.placement == PIC_PLACE_OFF) {
+    const hipError_t e = hipMalloc(&h->x, 2 * pbytes);
+    h->v = static_cast<char*>(h->x) + pbytes;
+    return e;
   }
-  st.seconds = seconds();
+  hipError_t e = hipMalloc(&h->x, pbytes);
+  if (e != hipSuccess) return e;
+  h->v_separate = true;
+  h->place_state.pbytes = pbytes;
+  placement_leg(h, pbytes);
+  if (!h->v) return hipMalloc(&h->v, pbytes);                          // no candidate at all (no memory to search in): plain allocation
   return hipSuccess;
+}
+
+// A reset replaces the particles: while the search has only ended for lack of time, and nobody outside has been given the arrays'
+// addresses, it may run another leg and move v for nothing.
+void resume_placement(pic_handle* h) {
+  PlacementState& ps = h->place_state;
+  if (!h->v_separate || ps.pbytes == 0 || ps.ptrs_exposed || ps.legs >= kMaxLegs || h->place.outcome != PIC_PLACED_TIMEOUT) return;
+  (void)hipStreamSynchronize(h->stream);
+  placement_leg(h, ps.pbytes);
 }
 
 int pic_create(const pic_config* cfg, pic_handle** out) {
@@ -1080,6 +1171,7 @@ int pic_refresh(pic_handle* h) {
 int pic_reset(pic_handle* h, const void* x0, const void* v0, int mem_kind) {
   if (!h) return PIC_EINVAL;
   HIPCHK(h, hipSetDevice(h->cfg.device_id));
+  resume_placement(h);
   HIPCHK(h, hipMemsetAsync(h->bad, 0, sizeof(unsigned long long), h->stream));
   int rc = pic_set_particles(h, x0, v0, mem_kind);
   if (rc) return rc;
@@ -1088,9 +1180,10 @@ int pic_reset(pic_handle* h, const void* x0, const void* v0, int mem_kind) {
 
 // the sweeps of one environment step; `upto`: 1 = through sweep B, 2 = through C, 3 = whole step.  from: first
 // stage to run (1, 2, 3).  Each force evaluation takes `ctl` (may differ per stage in the staged entry point).
-// another_step_follows (the steps of one call but the last): the post-step solve of this step is not launched; the
-// next step's sweep B carries it in one extra workgroup per environment (its results -- n, E_mesh, phi, the energies --
-// are read by nothing inside the call, and the last step's solve is a launch of its own as ever).
+// another_step_follows (the steps of one call but the last): this step ends with sweep D2, which leaves the deposit of its final
+// positions to the next step's sweep B2, and its post-step solve is not launched: that step's sweep C carries it in one extra
+// workgroup per environment (its results -- n, E_mesh, phi, the energies -- are read by nothing inside the call; the last step
+// ends with the full sweep D and a solve launch of its own as ever).  Every refresh is made, from the same integer sums.
 static void run_stages(pic_handle* h, int from, int upto, const Control& ctl, bool another_step_follows = false,
                        bool field_ready = false, const double* next_act = nullptr) {
   const double* c = h->cs;
@@ -1115,29 +1208,49 @@ static void run_stages(pic_handle* h, int from, int upto, const Control& ctl, bo
         launch_sweep(h, ST_A, h->x, h->v, 0.0, c[0], 0.0, -1, Control{}, ring_row(h, h->q_slot), nullptr);
       }
       const int x1 = ring_take_clean(h);
-      launch_sweep(h, ST_B, h->x, h->v, c[0], c[1], d[1], h->q_slot, first, ring_row(h, x1), nullptr, h->post_slot,
-                   share_field && !field_ready ? mine : nullptr);
-      ring_retire(h, h->post_slot);
-      h->post_slot = -1;
+      if (h->refresh_pending) {
+        // the step before ended with sweep D2: this sweep B deposits the positions it reads (that step's x') into row r, and sweep C
+        // carries the post-step solve of that step from it
+        const int r = ring_take_clean(h);
+        launch_sweep(h, ST_B2, h->x, h->v, c[0], c[1], d[1], h->q_slot, first, ring_row(h, x1), ring_row(h, r), -1,
+                     share_field && !field_ready ? mine : nullptr);
+        h->refresh_pending = false;
+        h->post_slot = r;
+      } else {
+        launch_sweep(h, ST_B, h->x, h->v, c[0], c[1], d[1], h->q_slot, first, ring_row(h, x1), nullptr, -1,
+                     share_field && !field_ready ? mine : nullptr);
+      }
       ring_retire(h, h->q_slot);
       h->q_slot = -1;
       h->stage_slot = x1;
     } else if (st == 2) {
       const int x2 = ring_take_clean(h);
-      launch_sweep(h, ST_C, h->x, h->v, 0.0, c[2], d[2], h->stage_slot, later, ring_row(h, x2), nullptr);
+      launch_sweep(h, ST_C, h->x, h->v, 0.0, c[2], d[2], h->stage_slot, later, ring_row(h, x2), nullptr, h->post_slot);
+      ring_retire(h, h->post_slot);
+      h->post_slot = -1;
       ring_retire(h, h->stage_slot);
       h->stage_slot = x2;
     } else {
-      const int f = ring_take_clean(h), qn = ring_take_clean(h);
       const bool hand_on = share_field && next_act != nullptr;
-      launch_sweep(h, ST_D, h->x, h->v, 0.0, c[3], d[3], h->stage_slot, later, ring_row(h, f), ring_row(h, qn), -1,
-                   hand_on ? other : nullptr, hand_on ? next_act : nullptr);
+      if (another_step_follows) {
+        // an inner step of a call: nothing can see its post-step fields before the next step has started, so the deposit they come
+        // from is left to that step's sweep B2 (sweep D is the one sweep bound by VALU issue: 336 -> 321 us at config 2, B 320 -> 322)
+        const int qn = ring_take_clean(h);
+        launch_sweep(h, ST_D2, h->x, h->v, 0.0, c[3], d[3], h->stage_slot, later, nullptr, ring_row(h, qn), -1,
+                     hand_on ? other : nullptr, hand_on ? next_act : nullptr);
+        h->refresh_pending = true;
+        h->post_hist_row = h->hist_row;
+        h->q_slot = qn;
+      } else {
+        const int f = ring_take_clean(h), qn = ring_take_clean(h);
+        launch_sweep(h, ST_D, h->x, h->v, 0.0, c[3], d[3], h->stage_slot, later, ring_row(h, f), ring_row(h, qn), -1,
+                     hand_on ? other : nullptr, hand_on ? next_act : nullptr);
+        launch_final_solve(h, f);
+        h->q_slot = qn;
+      }
       if (hand_on) h->ext_turn ^= 1;
       ring_retire(h, h->stage_slot);
       h->stage_slot = -1;
-      if (another_step_follows) { h->post_slot = f; h->post_hist_row = h->hist_row; }
-      else launch_final_solve(h, f);
-      h->q_slot = qn;
     }
   }
 }
@@ -1476,6 +1589,7 @@ int pic_get_particles(pic_handle* h, void* x, void* v, int mem_kind) {
 int pic_device_ptrs(pic_handle* h, void** x, void** v, int64_t* ld, double** n, double** E_mesh, double** phi,
                     double** KE, double** PE, double** PE_reward) {
   if (!h) return PIC_EINVAL;
+  if (x || v) h->place_state.ptrs_exposed = true;       // (from here on the search for a placement may not move v: resume_placement)
   if (x) *x = h->x;
   if (v) *v = h->v;
   if (ld) *ld = h->ld;
@@ -1856,6 +1970,7 @@ int pic_reset_sampled(pic_handle* h, int kind, double a, double v0, double sigma
   if (!h || (kind != 0 && kind != 1) || !(sigma > 0) || (kind == 1 && !(a >= 0)))
     return fail(h, PIC_EINVAL, "pic_reset_sampled: kind must be 0 (two-stream) or 1 (bump-on-tail), sigma > 0, a >= 0");
   HIPCHK(h, hipSetDevice(h->cfg.device_id));
+  resume_placement(h);
   const dim3 grid = aux_grid(h, h->cfg.num_envs, 2048);
   if (h->fmt == FMT_F64)
     hipLaunchKernelGGL(sample_kernel<PosF64>, grid, dim3(BLOCK), 0, h->stream, (double*)h->x, (double*)h->v, h->cfg.N,
