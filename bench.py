@@ -71,7 +71,10 @@ def pmc_traffic(kernel, args, E, N, Ng):
     path = os.path.join(ROOT, "profiles", PMC_SUMMARY)
     if not os.path.exists(path) or (E, N, Ng, args.dtype, args.positions) != (64, 1_000_000, 256, "float64", "float"):
         return None, None
-    val = json.load(open(path)).get("kernels", {}).get(kernel, {}).get("hbm_bytes_per_launch")
+    ks = json.load(open(path)).get("kernels", {})
+    # inside a multi-step call sweeps B and D run as B2 / D2: the counters of whichever form the collection launched more
+    forms = [k for k in (kernel, kernel + "2") if k in ks]
+    val = ks[max(forms, key=lambda k: ks[k].get("calls", 0))].get("hbm_bytes_per_launch") if forms else None
     return val, f"profiles/{PMC_SUMMARY} (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, " \
                 "not measured by this run)"
 

@@ -594,8 +594,10 @@ const char* pic_last_error(pic_handle* h) { return h ? h->err.c_str() : g_create
 //   here, a reading is one timed pass behind one untimed pass.
 // * What costs is hipMalloc of memory the device hands out for the first time since it came up: the driver clears it, 1.3 ms per
 //   512 MB block with the GPU otherwise idle and 3-6 ms under a streaming kernel (released memory is wiped in the background and
-//   comes back in 20-70 us).  A first create on such a device has x at the very start of a region, 31 GiB -- 80 to 200 ms of
-//   allocations -- from the first block that pairs well with it.  No budget that a constructor may take covers that.  But what one
+//   comes back in 20-70 us; a hipMalloc right behind the exit of a process that held tens of gigabytes can also sit and wait for
+//   that wipe, 0.6-1.5 s seen -- nothing a caller of hipMalloc can bound).  A first create on such a device has x at the very start
+//   of a region, 31 GiB -- 80 to 200 ms of allocations -- from the first block that pairs well with it.  No budget that a
+//   constructor may take covers that.  But what one
 //   leg has cleared and given back stays clean, so the NEXT leg walks through it in microseconds per block and spends its 100 ms
 //   beyond: pic_create runs the first leg, and while it ends for lack of time pic_reset / pic_reset_sampled -- which replace the
 //   particles anyway, so that moving v costs nothing -- run further ones (at most kMaxLegs, and only as long as pic_device_ptrs has
@@ -630,7 +632,10 @@ void placement_leg(pic_handle* h, size_t pbytes) {
   constexpr size_t kPatience = (size_t)42 << 30;    // walked without an improvement before giving up: more than the 32 GiB a region
                                                     // spans (15 GiB gave up inside x's own region on some boxes: 1049 instead of 958 us)
   constexpr int kMore = 16;                         // readings beyond the first that passes kGain
-  constexpr double kMaxSeconds = 0.100;             // per leg, the release of the blocks included
+  // per leg, the release of the blocks included: 100 ms, or what forty steps of the handle being placed take if that is more (a
+  // step moves 12 x pbytes at ~6 TB/s: 1 ms at config 2, 4 ms at config 4's share, 10 ms at config 5's -- whose 2-5 GB blocks cost
+  // 5-60 ms each to allocate on a device that hands them out for the first time)
+  const double kMaxSeconds = std::max(0.100, 40.0 * 12.0 * (double)pbytes / 6.0e12);
   constexpr double kFreeSeconds = 0.0002;           // what giving one block back costs (hipFree: 25 ms for 110 blocks)
   constexpr double kSlowPerGiB = 0.0008;            // a hipMalloc slower than this per GiB is clearing never-used memory
   constexpr int kMaxBlocks = 192;
@@ -677,7 +682,7 @@ void placement_leg(pic_handle* h, size_t pbytes) {
   if (ok) {
     feed.lead = lead_blocks;
     try {
-    feeder = std::thread([&feed, seconds, pbytes, budget, device]() {
+    feeder = std::thread([&feed, seconds, pbytes, budget, device, kMaxSeconds]() {
       const bool dev_ok = hipSetDevice(device) == hipSuccess;
       for (;;) {
         {

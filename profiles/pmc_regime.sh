@@ -28,7 +28,7 @@ for f in glob.glob(os.path.join(out, f"{tag}_g*", "**", "*_counter_collection.cs
     for r in csv.DictReader(open(f)):
         n = r["Kernel_Name"]
         if "sweep_kernel<" in n:
-            k = "sweep_" + "ABCDRP"[int(n.split("sweep_kernel<")[1].split(">")[0].split(",")[3])]
+            k = "sweep_" + ("A", "B", "C", "D", "R", "P", "B2", "D2")[int(n.split("sweep_kernel<")[1].split(">")[0].split(",")[3])]
         elif "resident_kernel" in n: k = "resident"
         elif "stream_probe" in n: k = "stream_probe"
         else: continue

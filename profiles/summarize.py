@@ -12,7 +12,8 @@ import json
 import os
 import sys
 
-STAGES = {"0": "sweep_A", "1": "sweep_B", "2": "sweep_C", "3": "sweep_D", "4": "sweep_refresh", "5": "sweep_probe"}
+STAGES = {"0": "sweep_A", "1": "sweep_B", "2": "sweep_C", "3": "sweep_D", "4": "sweep_refresh", "5": "sweep_probe",
+          "6": "sweep_B2", "7": "sweep_D2"}      # B2 / D2: sweeps B and D of the inner steps of a multi-step call
 
 
 def short(name):

@@ -290,6 +290,46 @@ def test_nsteps_in_one_call_equals_repeated_calls(oc, po):
     assert circ_err(xa[0], xa[1][::-1], L) / L < 1e-12 and rel_err(a.fields()[1][0], a.fields()[1][1]) < 1e-11
 
 
+@pytest.mark.parametrize("dtype,pos,interpol,accum", [("float64", None, "CIC", None), ("float64", None, "TSC", None),
+                                                     ("float32", None, "CIC", None),
+                                                     ("float32", "fixed32", "CIC", None), ("float32", None, "TSC", None),
+                                                     ("float32", "fixed32", "TSC", None)])
+def test_inner_steps_of_a_call_make_every_refresh_from_the_same_sums(oc, po, dtype, pos, interpol, accum):
+    """Inside a multi-step call of the streaming schedule a step ends with sweep D2 (no deposit of its final positions) and the next
+    step's sweep B2 makes that deposit from the positions it reads; sweep C carries the post-step solve (round 4).  Every step's
+    refresh must still be made, from the same integer sums: the energies of EVERY step, the fields and the particles of a K-step
+    call equal those of K one-step calls (which end with the full sweep D) bit for bit, in every particle format and shape --
+    and a second call right behind continues the same way."""
+    E_, N, Ng, L, K = 3, 20000, 96, 50.0, 6
+    xs, vs = zip(*[po.synthetic_two_stream(N, L, seed=70 + e) for e in range(E_)])
+    x0, v0 = np.stack(xs).astype(dtype), np.stack(vs).astype(dtype)
+    x0[x0 >= L] = 0.0
+    ext = 0.04 * np.random.default_rng(2).normal(size=(E_, Ng))
+    kw = dict(L=L, dt=0.1, dtype=dtype, position_dtype=pos, interpol=interpol, accum_dtype=accum, blocks_per_env=3)
+    a, b = oc.BatchedPIC(E_, N, Ng, **kw), oc.BatchedPIC(E_, N, Ng, **kw)
+    assert a._h.schedule() == "streaming"
+    for env in (a, b):
+        env.reset(x0, v0)
+    for field in (None, ext):
+        ke, pe, per = a.step_history(field, K)
+        for s in range(K):
+            b.step(field)
+            kb, pb, rb = b.energies()
+            assert np.array_equal(pe[s], pb) and np.array_equal(per[s], rb), (s, field is None)
+            assert np.allclose(ke[s], kb, rtol=1e-14)                      # (a float64 sum over workgroups in a fixed order)
+        for got, want in zip(a.fields(), b.fields()):
+            assert np.array_equal(got, want)
+        for got, want in zip(a.particles(), b.particles()):
+            assert np.array_equal(got, want)
+    a.step(None, K)                                                        # without history: the same schedule, nothing recorded
+    for _ in range(K):
+        b.step(None)
+    assert all(np.array_equal(p, q) for p, q in zip(a.particles() + a.fields(), b.particles() + b.fields()))
+    assert a.bad_count() == 0
+    a.close()
+    b.close()
+
+
 def test_energy_history_equals_stepwise_reads(oc, po):
     """pic_step_history / BatchedPIC.simulate: the E and PE traces of PIC.simulate, one read-back for all steps."""
     E_, N, Ng, L, K = 3, 20000, 128, 50.0, 12
