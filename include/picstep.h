@@ -81,6 +81,8 @@ typedef struct pic_config {
                               are handed over and returned as float32 like any float32 particle array; on the device
                               they are uint32 (pic_device_ptrs' x)                                                  */
   int32_t placement;       /* PIC_PLACE_AUTO | PIC_PLACE_OFF: see pic_placement_info                                */
+  int32_t placement_ms;    /* upper bound, in milliseconds, on one leg of the search for an (x, v) placement; 0 = the
+                              default (100 ms, or forty steps' worth of the handle if that is more)                  */
 } pic_config;
 
 typedef struct pic_handle pic_handle;

@@ -31,7 +31,7 @@ class PicConfig(C.Structure):
         ("L", C.c_double), ("n0", C.c_double), ("dt", C.c_double), ("gamma", C.c_double),
         ("particle_dtype", C.c_int32), ("accum_dtype", C.c_int32), ("interpol", C.c_int32),
         ("device_id", C.c_int32), ("blocks_per_env", C.c_int32), ("env_index_base", C.c_int32),
-        ("position_dtype", C.c_int32), ("placement", C.c_int32),
+        ("position_dtype", C.c_int32), ("placement", C.c_int32), ("placement_ms", C.c_int32),
     ]
 
 
@@ -155,7 +155,7 @@ class Handle:
 
     def __init__(self, N, Ng, num_envs=1, L=50.0, n0=1.0, dt=0.1, gamma=5.0, particle_dtype="float64",
                  accum_dtype=None, interpol="CIC", device_id=0, blocks_per_env=0, env_index_base=0,
-                 position_dtype=None, placement="auto"):
+                 position_dtype=None, placement="auto", placement_ms=0):
         self.lib = load()
         pd = {"float64": PIC_F64, "float32": PIC_F32}[str(np.dtype(particle_dtype))]
         # LDS mesh accumulator (include/picstep.h PIC_ACC_*).  None: the library's choice -- the packed word for
@@ -170,7 +170,7 @@ class Handle:
         self.cfg = PicConfig(int(N), int(Ng), int(num_envs), float(L), float(n0), float(dt), float(gamma), pd,
                              ACCUMULATORS[key], {"CIC": PIC_CIC, "TSC": PIC_TSC}[interpol], int(device_id),
                              int(blocks_per_env), int(env_index_base), POSITION_FORMATS[pkey],
-                             {"auto": 0, "off": 1}[placement])
+                             {"auto": 0, "off": 1}[placement], int(placement_ms))
         self.fixed_positions = POSITION_FORMATS[pkey] == PIC_POS_FIXED32
         self.N, self.Ng, self.num_envs = int(N), int(Ng), int(num_envs)
         self.dtype = np.dtype(particle_dtype)

@@ -103,6 +103,7 @@ struct pic_handle {
   bool v_separate = false;            // v is an allocation of its own (large states: alloc_particles)
   int post_slot = -1;                 // ring row whose post-step solve rides with the next sweep C (inside pic_step only)
   bool refresh_pending = false;       // the last sweep was a D2 (inside pic_step only): the next sweep B deposits the positions it reads
+  bool light_inner_steps = false;     // inner steps of a call end with sweep D2 (pic_create: states of 5e5 particles and more)
   double* hist_row = nullptr;         // where the NEXT post-step solve also records its three energies (step_recording), or null
   double* post_hist_row = nullptr;    // the same for the solve that post_slot stands for
   PlacementStats place{};             // what the search for an (x, v) placement did, all legs together (pic_placement_stats)
@@ -635,7 +636,7 @@ void placement_leg(pic_handle* h, size_t pbytes) {
   // per leg, the release of the blocks included: 100 ms, or what forty steps of the handle being placed take if that is more (a
   // step moves 12 x pbytes at ~6 TB/s: 1 ms at config 2, 4 ms at config 4's share, 10 ms at config 5's -- whose 2-5 GB blocks cost
   // 5-60 ms each to allocate on a device that hands them out for the first time)
-  const double kMaxSeconds = std::max(0.100, 40.0 * 12.0 * (double)pbytes / 6.0e12);
+  const double kMaxSeconds = h->cfg.placement_ms > 0 ? 1e-3 * h->cfg.placement_ms : std::max(0.100, 40.0 * 12.0 * (double)pbytes / 6.0e12);
   constexpr double kFreeSeconds = 0.0002;           // what giving one block back costs (hipFree: 25 ms for 110 blocks)
   constexpr double kSlowPerGiB = 0.0008;            // a hipMalloc slower than this per GiB is clearing never-used memory
   constexpr int kMaxBlocks = 192;
@@ -800,7 +801,7 @@ void placement_leg(pic_handle* h, size_t pbytes) {
   }
   if (outcome == PIC_PLACED_MEMORY && seconds() + kFreeSeconds * (double)feed.blocks.size() > kMaxSeconds)
     outcome = PIC_PLACED_TIMEOUT;                                     // (the feeder's own clock check)
-  if (found_at > 0 && outcome == PIC_PLACED_TIMEOUT) outcome = PIC_PLACED_FOUND;      // a fast pair is in hand: no further leg for the rest of the sixteen
+  if (found_at > 0) outcome = PIC_PLACED_FOUND;                       // a fast pair is in hand: no further leg for the rest of the sixteen
   (void)hipStreamSynchronize(h->stream);
   if (e0) hipEventDestroy(e0);
   if (e1) hipEventDestroy(e1);
@@ -878,6 +879,7 @@ int pic_create(const pic_config* cfg, pic_handle** out) {
     return fail(nullptr, PIC_EINVAL, "pic_create: the packed accumulator is CIC only");
   if (cfg->placement != PIC_PLACE_AUTO && cfg->placement != PIC_PLACE_OFF)
     return fail(nullptr, PIC_EINVAL, "pic_create: placement must be PIC_PLACE_AUTO or PIC_PLACE_OFF");
+  if (cfg->placement_ms < 0) return fail(nullptr, PIC_EINVAL, "pic_create: placement_ms < 0");
   if (cfg->accum_dtype == PIC_ACC_F64 && cfg->particle_dtype != PIC_F64)
     return fail(nullptr, PIC_EINVAL, "pic_create: the float64 accumulator needs float64 particles");
 
@@ -969,6 +971,10 @@ int pic_create(const pic_config* cfg, pic_handle** out) {
   // 3 / 4 environments of 1e6: 31.2 / 45.0 / 64.5 / 74.0 us per step with 4, 31.6 / 45.3 / 65.5 / 75.1 with 8, 33.3 / 47.8 /
   // 65.2 / 75.4 with 16: every reader sums them), at least 8 workgroups per sub-row; with 16 environments or more the rows
   // themselves spread the traffic (and the flushes hide under the streaming of the other workgroups).
+  // Inner steps of a multi-step call leave the deposit of their final positions to the next step's sweep B2 (run_stages) where the
+  // sweeps are bound by throughput; a single small environment is bound by the latency of each launch, and there the second mesh
+  // B2 has to clear and flush costs more than D2 saves (config 1 14.5 -> 14.7, one environment of N = 1e5 19.1 -> 19.4 us per step)
+  h->light_inner_steps = (double)cfg->N * cfg->num_envs >= 5.0e5;
   h->S = 1;
   while (h->S < 4 && nblk / (2 * h->S) >= 8 && (long long)cfg->num_envs * 2 * h->S <= 32) h->S *= 2;
 
@@ -1237,7 +1243,7 @@ static void run_stages(pic_handle* h, int from, int upto, const Control& ctl, bo
       h->stage_slot = x2;
     } else {
       const bool hand_on = share_field && next_act != nullptr;
-      if (another_step_follows) {
+      if (another_step_follows && h->light_inner_steps) {
         // an inner step of a call: nothing can see its post-step fields before the next step has started, so the deposit they come
         // from is left to that step's sweep B2 (sweep D is the one sweep bound by VALU issue: 336 -> 321 us at config 2, B 320 -> 322)
         const int qn = ring_take_clean(h);
@@ -1250,7 +1256,9 @@ static void run_stages(pic_handle* h, int from, int upto, const Control& ctl, bo
         const int f = ring_take_clean(h), qn = ring_take_clean(h);
         launch_sweep(h, ST_D, h->x, h->v, 0.0, c[3], d[3], h->stage_slot, later, ring_row(h, f), ring_row(h, qn), -1,
                      hand_on ? other : nullptr, hand_on ? next_act : nullptr);
-        launch_final_solve(h, f);
+        // (a small state's inner step: the full sweep D, its solve still not a launch -- it rides with the next step's sweep C)
+        if (another_step_follows) { h->post_slot = f; h->post_hist_row = h->hist_row; }
+        else launch_final_solve(h, f);
         h->q_slot = qn;
       }
       if (hand_on) h->ext_turn ^= 1;

@@ -22,7 +22,7 @@ class BatchedPIC:
     def __init__(self, num_envs: int, N: int, N_mesh: int, n0: float = 1.0, L: float = 50.0, dt: float = 0.1,
                  gamma: float = 5.0, interpol: str = "CIC", device: int = 0, dtype="float64", accum_dtype=None,
                  blocks_per_env: int = 0, verbose: bool = False, env_index_base: int = 0, position_dtype=None,
-                 placement: str = "auto"):
+                 placement: str = "auto", placement_ms: int = 0):
         self.num_envs, self.N, self.N_mesh = int(num_envs), int(N), int(N_mesh)
         self.n0, self.L, self.gamma, self.interpol = n0, L, gamma, interpol
         self.dx = L / N_mesh
@@ -35,7 +35,7 @@ class BatchedPIC:
         self.device = device
         self.dtype = np.dtype(dtype)
         self._h = _abi.Handle(self.N, self.N_mesh, self.num_envs, L, n0, self.dt, gamma, self.dtype, accum_dtype,
-                              interpol, device, blocks_per_env, env_index_base, position_dtype, placement)
+                              interpol, device, blocks_per_env, env_index_base, position_dtype, placement, placement_ms)
         self.fixed_positions = self._h.fixed_positions
 
     # reset(x0, v0): x0, v0 are [num_envs, N] with any velocity perturbation already applied

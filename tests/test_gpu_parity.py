@@ -294,13 +294,15 @@ def test_nsteps_in_one_call_equals_repeated_calls(oc, po):
                                                      ("float32", None, "CIC", None),
                                                      ("float32", "fixed32", "CIC", None), ("float32", None, "TSC", None),
                                                      ("float32", "fixed32", "TSC", None)])
-def test_inner_steps_of_a_call_make_every_refresh_from_the_same_sums(oc, po, dtype, pos, interpol, accum):
+@pytest.mark.parametrize("N", [20000, 200000])
+def test_inner_steps_of_a_call_make_every_refresh_from_the_same_sums(oc, po, N, dtype, pos, interpol, accum):
     """Inside a multi-step call of the streaming schedule a step ends with sweep D2 (no deposit of its final positions) and the next
     step's sweep B2 makes that deposit from the positions it reads; sweep C carries the post-step solve (round 4).  Every step's
     refresh must still be made, from the same integer sums: the energies of EVERY step, the fields and the particles of a K-step
     call equal those of K one-step calls (which end with the full sweep D) bit for bit, in every particle format and shape --
-    and a second call right behind continues the same way."""
-    E_, N, Ng, L, K = 3, 20000, 96, 50.0, 6
+    and a second call right behind continues the same way.  (States below 5e5 particles keep the full sweep D in their inner
+    steps, with the solve riding on the next sweep C: N = 20000 is that path, N = 200000 the D2 / B2 one.)"""
+    E_, Ng, L, K = 3, 96, 50.0, 6
     xs, vs = zip(*[po.synthetic_two_stream(N, L, seed=70 + e) for e in range(E_)])
     x0, v0 = np.stack(xs).astype(dtype), np.stack(vs).astype(dtype)
     x0[x0 >= L] = 0.0
@@ -1072,6 +1074,55 @@ def test_placement_search_frees_what_it_does_not_keep(oc):
         env.close()
     torch.cuda.synchronize()
     assert free0 - torch.cuda.mem_get_info()[0] < 32 << 20
+
+
+def test_placement_search_resumes_at_resets_until_the_addresses_are_out(oc):
+    """The search for an (x, v) placement runs in legs: pic_create runs one; while it has ended only for lack of time, every reset --
+    which replaces the particles anyway -- runs another (at most four in all) and may move v; once pic_device_ptrs has handed the
+    addresses out, v stays where it is.  A 1 ms budget per leg (pic_config.placement_ms) makes every leg run out of time; what the
+    handle computes is the same bits wherever v lies, and nothing of the search stays allocated."""
+    import torch
+    E_, N, Ng, L = 6, 3_000_000, 128, 50.0
+    oc.BatchedPIC(1, 1000, 32, L=L, dt=0.1).close()
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    ref = oc.BatchedPIC(E_, N, Ng, L=L, dt=0.1, placement="off")
+    ref.reset_sampled("bump-on-tail", seed=7)
+    ref.step(None, 3)
+    want = ref.particles() + ref.fields()
+    ref.close()
+    env = oc.BatchedPIC(E_, N, Ng, L=L, dt=0.1, placement_ms=1)
+    st = env._h.placement_stats()
+    assert st["legs"] == 1 and st["outcome"] in ("timeout", "found")     # ("found": a fast pair among the very first blocks)
+    legs = [st["legs"]]
+    for k in range(5):                                                   # resets run further legs, four in all at most
+        env.reset_sampled("bump-on-tail", seed=7)
+        st = env._h.placement_stats()
+        legs.append(st["legs"])
+        assert st["legs"] <= 4
+        if st["outcome"] != "timeout":
+            break
+    assert legs == sorted(legs)
+    if st["outcome"] == "timeout":
+        assert legs[-1] == 4 and legs[-2] == 4                           # the fifth reset ran none
+    env.step(None, 3)
+    got = env.particles() + env.fields()
+    assert all(np.array_equal(p, q) for p, q in zip(got, want))
+    held = free0 - torch.cuda.mem_get_info()[0]
+    state = 2 * E_ * N * 8
+    assert state <= held < state + (96 << 20), (held, state)             # x, v, meshes, staging: nothing of any leg
+    # a handle whose addresses are out keeps its v
+    other = oc.BatchedPIC(E_, N, Ng, L=L, dt=0.1, placement_ms=1)
+    ptr_v = other._h.device_ptrs()["v"]
+    before = other._h.placement_stats()["legs"]
+    other.reset_sampled("bump-on-tail", seed=7)
+    assert other._h.placement_stats()["legs"] == before and other._h.device_ptrs()["v"] == ptr_v
+    other.step(None, 3)
+    assert all(np.array_equal(p, q) for p, q in zip(other.particles() + other.fields(), want))
+    other.close()
+    env.close()
+    with pytest.raises(oc._abi.PicError, match="placement_ms"):
+        oc.BatchedPIC(1, 1000, 32, L=L, dt=0.1, placement_ms=-1)
 
 
 def test_placement_off_and_tight_memory(oc):

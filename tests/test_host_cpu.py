@@ -169,8 +169,8 @@ def test_sharded_env_resolves_its_device_once(monkeypatch):
 
 
 def test_config_struct_layout_matches_header():
-    # int64 N; int32 Ng, num_envs; 4 doubles; 8 int32
-    assert ctypes.sizeof(_abi.PicConfig) == 8 + 4 + 4 + 4 * 8 + 8 * 4
+    # int64 N; int32 Ng, num_envs; 4 doubles; 9 int32 (+ 4 bytes of tail padding to the 8-byte alignment)
+    assert ctypes.sizeof(_abi.PicConfig) == 8 + 4 + 4 + 4 * 8 + 9 * 4 + 4
     hdr = open(os.path.join(ROOT, "include", "picstep.h")).read()
     body = hdr[hdr.index("typedef struct pic_config {"):hdr.index("} pic_config;")]
     fields = re.findall(r"^\s*(?:int64_t|int32_t|double)\s+(\w+);", body, re.M)
