@@ -935,6 +935,12 @@ int pic_create(const pic_config* cfg, pic_handle** out) {
     if (small && max_by_work > 64) max_by_work = 64;
     if (nblk > max_by_work) nblk = max_by_work;
     if (nblk < 1) nblk = 1;
+    // ... and at most ~10 tiles (80 KB of x, 80 KB of v) per workgroup: a total of 8192 workgroups is 156 000 particles each at
+    // config 5's share -- 340 us per workgroup, and a last partial round of workgroups that long at the end of every sweep.  Scans
+    // of both large shares (profiles/bpe_big.sh): N = 4e6 x 64 float64 128 -> 384 workgroups per environment 4078 -> 3997 us per
+    // step (512: 4029), N = 1e7 x 128 float32 64 -> 512: 10223 -> 9913 (768: 9928, 1024: 10058); config 2 (122) is not touched.
+    const long long by10 = (cfg->N + 10 * tile - 1) / (10 * tile);
+    if (!small && nblk < by10) nblk = by10;
     // A handful of large environments run as one to six workgroups per CU: a total that fills the CUs unevenly leaves some
     // with one workgroup more than others for the whole sweep (3 x 1e6: 3 x 123 = 369 workgroups on 256 CUs 63.3 us/step, 3 x 163
     // = 489 58.9).  Take the workgroups per environment from the smallest k >= 2 workgroups per CU that keeps >= 8 tiles' worth
