@@ -31,11 +31,18 @@ def _line(cmd, extra_env=None, timeout=600):
     return json.loads(lines[0])
 
 
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return str(sk.getsockname()[1])
+
+
 def test_rccl_branch_with_one_rank():
     """torch.distributed.run --nproc-per-node 1: process group "nccl" (= RCCL) on cuda:0, the all-gather of returns and the
     max-over-ranks all-reduce really run through it."""
     out = _line([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
-                 "--master-port", "29541", os.path.join(ROOT, "bench.py"), "--gpus", "1"] + SMALL)
+                 "--master-port", _free_port(), os.path.join(ROOT, "bench.py"), "--gpus", "1"] + SMALL)
     assert out["collective_backend"] == "nccl" and out["n_gpus"] == 1
     assert len(out["returns_all_gather_ms"]) == 1 and math.isfinite(out["returns_all_gather_ms"][0])
     assert out["returns_all_gather_ms"][0] >= 0.0 and len(out["per_rank_ms_per_step"]) == 1
