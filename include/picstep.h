@@ -276,8 +276,8 @@ int pic_schedule(pic_handle* h);
 /* Particle states of 256 MB and more: x and v are two allocations, and pic_create times a streaming pass over (x, candidate
  * block for v) for a series of candidate blocks: on MI355X two arrays stream together at 6.05 TB/s when they lie in different
  * 32 GiB regions of HBM and at 5.25 TB/s when they share one.  The search stops sixteen readings after the best pair
- * seen is 10 % faster than the slowest seen (keeping the best of all), after 42 GiB walked without an improvement (more than a
- * 32 GiB region), or when a third of the device's free memory is held; no absolute rate enters.  It runs in LEGS of at most 100 ms
+ * seen is 10 % faster than the slowest seen (keeping the best of all), after 42 GiB and sixteen blocks walked without an improvement
+ * (more than a 32 GiB region), or when a third of the device's free memory is held; no absolute rate enters.  It runs in LEGS of at most 100 ms
  * (or forty steps' worth of the handle being placed, if that is more: 160 ms at N = 4e6 x 64, 410 ms at N = 1e7 x 128 float32):
  * pic_create runs one; while the search has ended only for lack of time (outcome PIC_PLACED_TIMEOUT: on a device whose memory is
  * handed out for the first time hipMalloc clears it at 1.3-6 ms per 512 MB block, and the first block that pairs well with x can be

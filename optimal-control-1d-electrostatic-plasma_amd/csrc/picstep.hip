@@ -789,7 +789,8 @@ void placement_leg(pic_handle* h, size_t pbytes) {
       if (timed - found_at >= kMore) { outcome = PIC_PLACED_FOUND; break; }
       continue;
     }
-    if ((last - best_at) * pbytes >= kPatience) { outcome = PIC_PLACED_PATIENCE; break; }
+    // (for the 2-5 GB blocks of configs 4 and 5 that is sixteen blocks at least: nine alike have been followed by a fast one)
+    if ((last - best_at) * pbytes >= kPatience && last - best_at >= 16) { outcome = PIC_PLACED_PATIENCE; break; }
   }
   if (feeder.joinable()) {
     {
