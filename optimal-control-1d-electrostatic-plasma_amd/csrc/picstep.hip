@@ -103,7 +103,7 @@ struct pic_handle {
   bool v_separate = false;            // v is an allocation of its own (large states: alloc_particles)
   int post_slot = -1;                 // ring row whose post-step solve rides with the next sweep C (inside pic_step only)
   bool refresh_pending = false;       // the last sweep was a D2 (inside pic_step only): the next sweep B deposits the positions it reads
-  bool light_inner_steps = false;     // inner steps of a call end with sweep D2 (pic_create: states of 5e5 particles and more)
+  bool light_inner_steps = false;     // inner steps of a call end with sweep D2 (pic_create: particle states of 256 MB and more)
   double* hist_row = nullptr;         // where the NEXT post-step solve also records its three energies (step_recording), or null
   double* post_hist_row = nullptr;    // the same for the solve that post_slot stands for
   PlacementStats place{};             // what the search for an (x, v) placement did, all legs together (pic_placement_stats)
@@ -979,9 +979,11 @@ int pic_create(const pic_config* cfg, pic_handle** out) {
   // 65.2 / 75.4 with 16: every reader sums them), at least 8 workgroups per sub-row; with 16 environments or more the rows
   // themselves spread the traffic (and the flushes hide under the streaming of the other workgroups).
   // Inner steps of a multi-step call leave the deposit of their final positions to the next step's sweep B2 (run_stages) where the
-  // sweeps are bound by throughput; a single small environment is bound by the latency of each launch, and there the second mesh
-  // B2 has to clear and flush costs more than D2 saves (config 1 14.5 -> 14.7, one environment of N = 1e5 19.1 -> 19.4 us per step)
-  h->light_inner_steps = (double)cfg->N * cfg->num_envs >= 5.0e5;
+  // sweeps are bound by HBM -- a particle state that does not fit the 256 MB Infinity Cache: there sweep B has the issue slots that
+  // sweep D lacks (config 2 969 -> 948 us per step).  States that live in the cache, or are bound by the latency of each launch,
+  // gain nothing or lose (all measured on one box, round 3's tree against this one: 8 x 1e6 float64 131.2 -> 132.6, 64 x 20000
+  // float32 TSC 26.2 -> 27.2, config 1 14.5 -> 14.7, one environment of N = 1e5 19.1 -> 19.4): they keep the full sweep D.
+  h->light_inner_steps = 2.0 * (double)cfg->num_envs * (double)h->ld * (double)h->esz >= 256.0 * 1048576.0;
   h->S = 1;
   while (h->S < 4 && nblk / (2 * h->S) >= 8 && (long long)cfg->num_envs * 2 * h->S <= 32) h->S *= 2;
 
