@@ -340,10 +340,32 @@ def composed_loops(only=()):
         out.update(x=np.array(xs), v=np.array(vs), E_mesh=np.array(Es), H=np.array(Hs), calls_per_step=np.array(ncalls))
         save("g15_input_func", **out)
 
+    # ---- G16: PIC.compute_state_gradient (pic.py:125-129) on arbitrary states, and what reinit() leaves (pic.py:84-91) ---------
+    if want("g16"):
+        N, Ng = 2500, 96
+        np.random.seed(53)
+        sim = PIC(N=N, N_mesh=Ng, n0=1.0, L=L, dt=0.1, tmin=0.0, tmax=50.0, gamma=5.0, A=0.1, n_mode=2, interpol="CIC",
+                  init_dist=BumpOnTail(a=0.2, v0=3.0, sigma=1.0, n_samples=N, L=L))
+        grng = np.random.default_rng(1653)
+        eta = np.concatenate([grng.uniform(-0.7 * L, 1.9 * L, (N, 1)), grng.normal(0, 2, (N, 1))], axis=0)   # positions outside [0, L) too
+        ext = E_field(L, Ng, 4).compute_E(grng.uniform(-1, 1, 4), grng.uniform(-1, 1, 4))
+        out = dict(L=L, Ng=Ng, N=N, n0=1.0, eta=eta.copy(), E_ext=ext)
+        e1 = eta.copy(); g1 = sim.compute_state_gradient(e1, None)
+        e2 = eta.copy(); g2 = sim.compute_state_gradient(e2, ext)
+        out.update(grad_free=g1, grad_ext=g2, eta_after=e1)       # compute_E wraps eta[:N] in place (util.py:51)
+        sim.update_state(None)
+        out.update(x_before=sim.x.copy(), E_mesh_before=sim.E_mesh.copy())
+        sim.reinit()                                               # a fresh sample from the global RNG, fields set to None
+        out.update(x_reinit=sim.x.copy(), v_reinit=sim.v.copy(), n_reinit=sim.n.copy(),
+                   fields_none=np.array([sim.E is None, sim.E_mesh is None, sim.phi_mesh is None]))
+        sim.update_state(None)
+        out.update(x_after=sim.x.copy(), v_after=sim.v.copy(), E_mesh_after=sim.E_mesh.copy(), H_after=sim.get_energy())
+        save("g16_gradient_reinit", **out)
+
 
 if __name__ == "__main__":
-    # `make_golden.py g12 g13 g14 g15` regenerates only the named composed-loop fixtures; no argument = everything
-    sel = tuple(a for a in sys.argv[1:] if a in ("g12", "g13", "g14", "g15"))
+    # `make_golden.py g12 ... g16` regenerates only the named fixtures of round 4; no argument = everything
+    sel = tuple(a for a in sys.argv[1:] if a in ("g12", "g13", "g14", "g15", "g16"))
     if sel:
         _import_reference()
         composed_loops(sel)

@@ -1,10 +1,11 @@
 """The reference's own LOOPS around the step, against fixtures the reference itself produced (tests/golden/make_golden.py,
-composed_loops: G12-G15, round 4):
+composed_loops: G12-G16, round 4):
 
   G12  run_feedback.py:130-168        the closed feedback loop (two-stream, N = 5000, Ng = 250, max_mode = 5, 50 steps)
   G13  src/env/pic.py:175-223         PIC.simulate with and without a field trajectory
   G14  src/control/rl/ddpg.py:364-381 the behaviour-cloning rollout with its hard-coded spectrum arguments (n0 = 1, L = 50, Ng = 250)
   G15  src/env/pic.py:148-163         update_state_w_input_func with a pure function of the sub-stage state
+  G16  src/env/pic.py:125-129, 84-91  compute_state_gradient on arbitrary states; reinit() and the step after it
 
 Each loop is run (a) as the reference writes it, with this package's objects in the reference's places, and (b) through the one-call
 entry points that replace it on the device (pic_step_feedback, pic_step_ext_traj, pic_step_snapshots), on both schedules.  Bounds
@@ -305,4 +306,38 @@ def test_g15_update_state_w_input_func(oc):
     for name, val in worst.items():
         record_measure(f"g15.{name}", val)
     assert worst["calls"] < 1e-13 and worst["x"] < TOL_X and worst["v"] < TOL_V and worst["E_mesh"] < TOL_E and worst["H"] < TOL_H
+    sim.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# G16: PIC.compute_state_gradient on arbitrary states, and what reinit() leaves
+# ---------------------------------------------------------------------------------------------------------------------
+def test_g16_state_gradient_and_reinit(oc):
+    """pic.py:125-129 with positions outside [0, L) -- the reference's compute_E wraps eta[:N] in place (util.py:51), and so does the
+    drop-in's -- with and without an external field; then reinit() (pic.py:84-91): a fresh sample from the global RNG (the same
+    draws as the reference's, g10), E / E_mesh / phi_mesh None until the next step, and that step against the reference's."""
+    g = load_golden("g16_gradient_reinit")
+    L, Ng, N = float(g["L"]), int(g["Ng"]), int(g["N"])
+    np.random.seed(53)
+    sim = oc.PIC(N=N, N_mesh=Ng, n0=1.0, L=L, dt=0.1, tmin=0.0, tmax=50.0, gamma=5.0, A=0.1, n_mode=2, interpol="CIC",
+                 init_dist=oc.BumpOnTail(a=0.2, v0=3.0, sigma=1.0, n_samples=N, L=L))
+    for ext, key in ((None, "grad_free"), (g["E_ext"], "grad_ext")):
+        eta = g["eta"].copy()
+        out = sim.compute_state_gradient(eta, ext)
+        assert out.shape == (2 * N, 1) and np.array_equal(out[:N], g[key][:N])
+        e = rel_err(out[N:], g[key][N:])
+        record_measure(f"g16.{key}", e)
+        assert e < 1e-11
+        assert np.array_equal(eta, g["eta_after"])                      # wrapped in place, like the reference's
+    sim.update_state(None)
+    assert circ_err(sim.x, g["x_before"], L) / L < TOL_X and rel_err(sim.E_mesh, g["E_mesh_before"]) < TOL_E
+    sim.reinit()
+    assert np.array_equal(sim.x, g["x_reinit"]) and np.array_equal(sim.v, g["v_reinit"])
+    assert sim.E is None and sim.E_mesh is None and sim.phi_mesh is None and bool(g["fields_none"].all())
+    assert rel_err(sim.n, g["n_reinit"]) < 1e-13
+    sim.update_state(None)
+    ex, ev, eE = circ_err(sim.x, g["x_after"], L) / L, rel_err(sim.v, g["v_after"]), rel_err(sim.E_mesh, g["E_mesh_after"])
+    for name, val in (("x_after", ex), ("v_after", ev), ("E_mesh_after", eE)):
+        record_measure(f"g16.{name}", val)
+    assert ex < TOL_X and ev < TOL_V and eE < TOL_E and abs(sim.get_energy() / float(g["H_after"]) - 1) < TOL_H
     sim.close()

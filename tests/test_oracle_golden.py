@@ -259,3 +259,20 @@ def test_g15_update_state_w_input_func():
                 assert rel_err(calls[i][:, 0], c) < 1e-13
         assert rel_err(ref.x[:, 0], g["x"][k]) < 1e-11 and rel_err(ref.v[:, 0], g["v"][k]) < 1e-11
         assert rel_err(ref.E_mesh[:, 0], g["E_mesh"][k]) < 1e-9 and abs(ref.get_energy() / g["H"][k] - 1) < 1e-12
+
+
+def test_g16_state_gradient_and_reinit():
+    """pic.py:125-129 on a state with positions outside [0, L) (the in-place wrap of util.py:51 included), and the step after a
+    reinit from the particles the reference drew."""
+    g = load_golden("g16_gradient_reinit")
+    L, Ng, N = float(g["L"]), int(g["Ng"]), int(g["N"])
+    sim = po.OraclePIC(g["x_reinit"], g["v_reinit"], Ng, L=L, dt=0.1, perturb=False, faithful=False)
+    for ext, key in ((None, "grad_free"), (g["E_ext"], "grad_ext")):
+        eta = g["eta"].copy()
+        out = sim.state_gradient(eta, ext)
+        assert np.array_equal(out[:N], g[key][:N]) and rel_err(out[N:], g[key][N:]) < 1e-12
+        assert np.array_equal(eta, g["eta_after"])
+    assert np.array_equal(sim.n, g["n_reinit"])
+    sim.update_state(None)
+    assert rel_err(sim.x, g["x_after"]) < 1e-12 and rel_err(sim.E_mesh, g["E_mesh_after"]) < 1e-10
+    assert abs(sim.get_energy() / float(g["H_after"]) - 1) < 1e-13
